@@ -1,0 +1,212 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY (development container only).
+
+Imports the reference implementation from /root/reference (CPU, fp32), checks
+the restatement in oracle/sconformer_ref.py against it, and writes the golden
+fixtures under tests/golden/ that pin both the oracle and the HIP path.  This
+script is inert on the GPU box (no /root/reference there); the fixtures it
+writes are plain .npz data (inputs + expected outputs), loadable with
+numpy.load(allow_pickle=False).
+
+Loader shim: SURVEY.md appendix A.5 (skips the package __init__s that pull
+torchaudio/librosa/jiwer, which are not needed on the hot path).
+
+Usage:  python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+import warnings
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = '/root/reference'
+GOLD = os.path.join(ROOT, 'tests', 'golden')
+
+
+def load_reference():
+    sys.path.insert(0, REF)
+    for name, path in [('lcasr', REF + '/lcasr'), ('lcasr.utils', REF + '/lcasr/utils'),
+                       ('lcasr.models', REF + '/lcasr/models'), ('lcasr.optim', REF + '/lcasr/optim')]:
+        m = types.ModuleType(name); m.__path__ = [path]; sys.modules[name] = m
+    oc = types.ModuleType('omegaconf'); oc2 = types.ModuleType('omegaconf.omegaconf')
+    oc2.OmegaConf = object; oc.omegaconf = oc2; oc.OmegaConf = object
+    sys.modules['omegaconf'] = oc; sys.modules['omegaconf.omegaconf'] = oc2
+    warnings.filterwarnings('ignore')
+    from lcasr.models.sconformer_xl import SCConformerXL
+    from lcasr.components.attention import attention_ref
+    from lcasr.optim.madgrad import MADGRAD
+    return SCConformerXL, attention_ref, MADGRAD
+
+
+TINY = dict(vocab_size=127, n_layers=2, d_model=64, n_heads=2, head_dim=32, subsampling_conv_channels=32,
+            use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True, bias_in_ff=False)
+C1 = dict(vocab_size=4095, n_layers=6, d_model=256, n_heads=8, head_dim=32, subsampling_conv_channels=256,
+          use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True, bias_in_ff=False,
+          default_norm='layer_norm')
+
+
+def synth(B, T, V, lengths=None, seed=0):
+    """SURVEY §8(d) synthetic inputs: mel ~ N(0,1) (B,80,T), targets uniform [0,V), S=N/4."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 80, T, generator=g)
+    N = T // 8
+    S = max(N // 4, 1)
+    tg = torch.randint(0, V, (B, S), generator=g)
+    ln = torch.tensor(lengths if lengths is not None else [T] * B)
+    # per-sample target length: a quarter of that sample's token count (always CTC-feasible)
+    tl = torch.tensor([max(1, min(S, ((int(l) - 1) // 8 + 1) // 4)) for l in ln], dtype=torch.long)
+    return x, ln, tg, tl
+
+
+def np_sd(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items()}
+
+
+def run_case(SC, kw, B, T, lengths, tag, save_all_grads=True, save_weights=True, max_abs_tol=2e-5):
+    from oracle import sconformer_ref as O
+    torch.manual_seed(12345)                                   # exp/train.py:363
+    model = SC(**kw)
+    model.train()
+    V = kw['vocab_size']
+    x, ln, tg, tl = synth(B, T, V, lengths)
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    caps = {}
+    hooks = []
+    def hook(name):
+        def f(mod, inp, out):
+            caps[name] = (out[0] if isinstance(out, tuple) else out).detach().clone()
+        return f
+    hooks.append(model.subsampling.register_forward_hook(hook('sub.out')))
+    for i, l in enumerate(model.layers):
+        hooks.append(l.register_forward_hook(hook(f'layers.{i}.out')))
+        hooks.append(l.attend.register_forward_hook(hook(f'layers.{i}.attend.branch')))
+        hooks.append(l.conv.register_forward_hook(hook(f'layers.{i}.conv.branch')))
+        hooks.append(l.ff1.register_forward_hook(hook(f'layers.{i}.ff1.branch')))
+
+    out = model(x, length=ln)
+    lp = out['final_posteriors']
+    ctc = torch.nn.CTCLoss(blank=model.decoder.num_classes - 1, reduction='sum')   # exp/train.py:104
+    loss = ctc(lp.transpose(0, 1), tg, out['length'], tl).sum()                     # exp/train.py:249
+    scaled = loss / (T * B) * 100                                                   # exp/train.py:275
+    lp.retain_grad()
+    scaled.backward()
+    for h in hooks: h.remove()
+    ref_grads = {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    sd1 = {k: v.clone() for k, v in model.state_dict().items()}
+
+    # ---- oracle on the same weights -------------------------------------
+    cfg = O.make_config(**kw)
+    sdo = {k: v.clone().requires_grad_(v.is_floating_point() and k in ref_grads) for k, v in sd0.items()}
+    nb, cap = {}, {}
+    oloss, oscaled, oout = O.train_step_loss(sdo, cfg, x, ln, tg, tl, new_buffers=nb)
+    oout['final_posteriors'].retain_grad()
+    oscaled.backward()
+    def md(a, b): return float((a - b).abs().max())
+    errs = {'logp': md(oout['final_posteriors'], lp), 'loss': abs(float(oloss) - float(loss)) / abs(float(loss))}
+    # dw-conv bias grads are analytically 0 (BatchRenorm removes the mean): compare on an absolute floor
+    gmax = max(float(v.abs().max()) for v in ref_grads.values())
+    zero_keys = [k for k in ref_grads if k.endswith('depthwise_conv.bias')]        # pure cancellation noise
+    errs['grad'] = max(md(sdo[k].grad, ref_grads[k]) / max(float(ref_grads[k].abs().max()), 1e-3 * gmax)
+                       for k in ref_grads if k not in zero_keys)
+    errs['grad0'] = max(md(sdo[k].grad, ref_grads[k]) / gmax for k in zero_keys)
+    errs['buf'] = max(md(nb[k].float(), sd1[k].float()) for k in nb)
+    assert (oout['length'] == out['length']).all()
+    print(f'[{tag}] loss={float(loss):.6f} oracle-vs-reference:', {k: f'{v:.2e}' for k, v in errs.items()})
+    assert errs['logp'] < max_abs_tol and errs['loss'] < 1e-5 and errs['grad'] < 1e-3 and errs['grad0'] < 1e-4 and errs['buf'] < 1e-6, errs
+
+    fx = dict(x=x.numpy(), lengths=ln.numpy(), targets=tg.numpy(), target_lengths=tl.numpy(),
+              out_length=out['length'].numpy(), loss=np.float64(float(loss)), scaled_loss=np.float64(float(scaled)))
+    for k, v in kw.items():
+        fx['cfg.' + k] = np.array(v)
+    if save_weights:
+        for k, v in np_sd(sd0).items(): fx['w.' + k] = v
+        fx['logp'] = lp.detach().numpy()
+        fx['dlogp'] = lp.grad.detach().numpy()
+        for k, v in caps.items(): fx['cap.' + k] = v.numpy()
+        for k in nb: fx['buf.' + k] = sd1[k].numpy()
+    else:
+        fx['logp_slice'] = lp.detach()[:, ::17, ::97].numpy()
+        fx['logp_sum'] = np.float64(float(lp.detach().double().sum()))
+        fx['logp_abs_sum'] = np.float64(float(lp.detach().double().abs().sum()))
+    if save_all_grads:
+        for k, v in ref_grads.items(): fx['g.' + k] = v.numpy()
+    else:
+        for k, v in ref_grads.items(): fx['gnorm.' + k] = np.float64(float(v.double().norm()))
+    np.savez_compressed(os.path.join(GOLD, tag + '.npz'), **fx)
+    return model
+
+
+def attention_cases(attention_ref):
+    """F3/F4: flash-attn semantics (incl. local window) from attention.py:330-410 — the only
+    CPU-runnable definition of window_size in the reference."""
+    from oracle import sconformer_ref as O
+    g = torch.Generator().manual_seed(3)
+    fx = {}
+    for name, (B, N, H, D, win, lens) in {
+        'full_d128': (1, 256, 2, 128, (-1, -1), None),
+        'full_d32': (2, 192, 4, 32, (-1, -1), [192, 100]),
+        'win_d32': (2, 160, 2, 32, (16, 16), None),
+        'win_asym_d128': (1, 128, 2, 128, (24, 8), None),
+    }.items():
+        q, k, v = (torch.randn(B, N, H, D, generator=g) for _ in range(3))
+        kpm = None
+        if lens is not None:
+            kpm = torch.arange(N)[None, :] < torch.tensor(lens)[:, None]
+        o, _ = attention_ref(q, k, v, query_padding_mask=kpm, key_padding_mask=kpm, window_size=win, upcast=True)
+        fx[name + '.q'], fx[name + '.k'], fx[name + '.v'], fx[name + '.o'] = q.numpy(), k.numpy(), v.numpy(), o.numpy()
+        fx[name + '.window'] = np.array(win)
+        fx[name + '.lens'] = np.array(lens if lens is not None else [N] * B)
+    np.savez_compressed(os.path.join(GOLD, 'attention.npz'), **fx)
+    print('[attention] wrote', len(fx), 'arrays')
+
+
+def madgrad_case(MADGRAD):
+    from oracle import madgrad_ref as M
+    g = torch.Generator().manual_seed(5)
+    shapes = [(37,), (8, 16), (3, 5, 7)]
+    params = [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+    opt = MADGRAD(params, lr=3e-3, momentum=0.9, weight_decay=0.0, eps=1e-6)
+    fx = {}
+    for i, p in enumerate(params): fx[f'p0.{i}'] = p.detach().numpy().copy()
+    # oracle state
+    st = [dict(p=p.detach().numpy().copy(), gss=np.zeros(p.shape, np.float32), s=np.zeros(p.shape, np.float32),
+               x0=p.detach().numpy().copy()) for p in params]
+    for step in range(4):
+        grads = [torch.randn(*s, generator=g) * (10.0 if step == 1 else 0.1) for s in shapes]
+        for i, gr in enumerate(grads): fx[f'g{step}.{i}'] = gr.numpy().copy()
+        for p, gr in zip(params, grads): p.grad = gr.clone()
+        torch.nn.utils.clip_grad_norm_(params, 0.8)             # exp/train.py:55
+        opt.step()
+        coef, _ = M.clip_coef([x.numpy() for x in grads], 0.8)
+        for i, gr in enumerate(grads):
+            s_ = st[i]
+            s_['p'], s_['gss'], s_['s'] = M.madgrad_step(s_['p'], gr.numpy() * np.float32(coef), s_['gss'], s_['s'], s_['x0'], step, 3e-3)
+            err = np.abs(s_['p'] - params[i].detach().numpy()).max()
+            assert err < 1e-6, (step, i, err)
+        for i, p in enumerate(params): fx[f'p{step + 1}.{i}'] = p.detach().numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, 'madgrad.npz'), **fx)
+    print('[madgrad] oracle matches reference; wrote fixture')
+
+
+def main():
+    assert os.path.isdir(REF), 'reference not present: this script only runs in the development container'
+    os.makedirs(GOLD, exist_ok=True)
+    SC, attention_ref, MADGRAD = load_reference()
+    torch.set_num_threads(8)
+    run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200], 'tiny_ln_ragged')
+    run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, None, 'tiny_ln_equal')
+    run_case(SC, dict(TINY, default_norm='rms_norm'), 2, 256, [256, 200], 'tiny_rms_ragged')
+    run_case(SC, dict(TINY, default_norm='layer_norm'), 3, 1000, [1000, 1023 - 40, 17 * 8], 'tiny_ln_odd')
+    run_case(SC, C1, 2, 1024, None, 'c1_scalars', save_all_grads=False, save_weights=False, max_abs_tol=2e-4)
+    attention_cases(attention_ref)
+    madgrad_case(MADGRAD)
+
+
+if __name__ == '__main__':
+    main()
