@@ -1,0 +1,123 @@
+/* sconf.h — C ABI of libsconf_hip.so: the MI355X (gfx950) SConformerXL hot path.
+ *
+ * Drop-in boundary.  The reference (robflynnyh/long-context-asr, `lcasr`) has no FFI of its
+ * own: its seams are the optional native ops it imports inside try/except.  Each entry point below names
+ * the reference interface (file:line under /root/reference) it replaces.  Conventions:
+ *   - plain pointers + sizes, no torch types; every pointer is a DEVICE pointer unless stated otherwise;
+ *   - all buffers are caller-owned and only borrowed for the enqueued work; kernels are enqueued on `stream`
+ *     and never synchronise, allocate or free (graph-capture safe);
+ *   - return 0 on success, non-zero on error with a message in sconf_last_error() (thread-local);
+ *   - dtype enums: 0 = float32, 1 = bfloat16.  "ACCUMULATED" outputs are += with f32 atomics.
+ */
+#ifndef SCONF_H
+#define SCONF_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* sconf_stream_t; /* == hipStream_t */
+
+enum { SCONF_F32 = 0, SCONF_BF16 = 1 };
+enum { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4 };
+enum { SCONF_GEMM_NT = 0, SCONF_GEMM_NN = 1, SCONF_GEMM_TN = 2 };
+enum { SCONF_NORM_LAYER = 0, SCONF_NORM_RMS = 1, SCONF_NORM_RMS_APEX = 2 };
+
+const char* sconf_last_error(void);
+int sconf_version(void);
+int sconf_num_cus(void);
+
+/* C[M,N] = resid + alpha * act(A·B + bias), bf16 operands, f32 accumulate (MFMA).
+ * layout NT: A[M][K], B[N][K]  (F.linear / fused_dense_cuda.linear_act_forward, fused_dense.py:277-279,329-332,465-469)
+ * layout NN: A[M][K], B[K][N]  (dgrad: fused_dense_cuda.bias_act_linear_dgrad_bgrad, fused_dense.py:354-356)
+ * layout TN: A[K][M], B[K][N]  (wgrad: fused_dense_cuda.linear_bias_wgrad, fused_dense.py:113-115,338-340,375-378)
+ * act DGELU/DSILU multiply by act'(aux[M][N]); pre (nullable) receives A·B+bias in bf16 (save_pre_act);
+ * split_k > 1 accumulates into a PRE-ZEROED f32 C with atomics (plain epilogue only). */
+int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K,
+                    int64_t lda, int64_t ldb, int64_t ldc, const float* bias, const float* resid, int64_t ldr,
+                    const void* aux, int64_t ldaux, void* pre, int64_t ldpre, float alpha, int act, int out_f32,
+                    int split_k, sconf_stream_t stream);
+
+/* Row norms over the last dim d <= 2048 (apex FusedLayerNorm/FusedRMSNorm, torch LayerNorm, local RMSNorm:
+ * sconformer_xl.py:14-17, normalisation.py:6-47).  mean/rstd: f32 [M] saved statistics. */
+int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
+                   float* mean, float* rstd, int64_t M, int64_t d, float eps, sconf_stream_t stream);
+/* dx = (dres ? dres : 0) + norm'(x)·dy ; dweight/dbias ACCUMULATED. */
+int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
+                   const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype, float* dweight,
+                   float* dbias, int64_t M, int64_t d, float eps, sconf_stream_t stream);
+
+int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
+
+/* qkv de-interleave "b n (h d qkv) -> qkv b n h d" + NeoX rotary on q,k (attention.py:485,498-507; rotary_emb.py:61-73).
+ * bwd != 0: transpose, (dq,dk,dv) -> dqkv written to `qkv`.  cos/sin: f32 [N][D/2]. */
+int sconf_rotary_qkv(int bwd, void* qkv, const float* cos_tab, const float* sin_tab, void* q, void* k, void* v,
+                     int64_t B, int64_t N, int64_t H, int64_t D, int use_rotary, sconf_stream_t stream);
+
+/* mode 0 softmax (sconformer_xl.py:242), mode 1 log_softmax (decoder.py:25); C <= 8192 classes. */
+int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, int y_dtype, int64_t M, int64_t C, sconf_stream_t stream);
+int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype,
+                      int64_t M, int64_t C, sconf_stream_t stream);
+
+/* out[n] += sum_m x[m][n]  (bias gradients). */
+int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, sconf_stream_t stream);
+/* zero rows n >= lengths[b] of x[B][N][d] in place (attention.py:511,546-547; convolution.py:109-110). */
+int sconf_mask_rows(void* x, int dtype, const int32_t* lengths, int64_t B, int64_t N, int64_t d, sconf_stream_t stream);
+
+/* Flash attention, bidirectional, head_dim 32 or 128; replaces FlashSelfAttention.forward(qkv[,key_padding_mask],
+ * cu_seqlens, max_seqlen) = flash_attn_qkvpacked_func / flash_attn_varlen_qkvpacked_func (attention.py:200-257,
+ * 527-535) and F.scaled_dot_product_attention (attention.py:541).  q,k,v,o: bf16 (B,N,H,D) views with element
+ * strides {batch, token, head}; lengths: int32 [B] or NULL; window (-1 = unbounded); lse: f32 (B,H,N). */
+int sconf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* lengths,
+                   int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* q_strides /*host*/, const int64_t* k_strides /*host*/,
+                   const int64_t* v_strides /*host*/, const int64_t* o_strides /*host*/, int win_left, int win_right,
+                   float scale, sconf_stream_t stream);
+int sconf_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                   float* delta, void* dq, void* dk, void* dv, const int32_t* lengths, int64_t B, int64_t N, int64_t H,
+                   int64_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                   const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
+                   const int64_t* dv_strides, int win_left, int win_right, float scale, sconf_stream_t stream);
+
+/* Conformer conv module, token-major (convolution.py:103-124; conv1dFunc seam convolution.py:6-22; batchrenorm.py:52-92). */
+int sconf_glu_dwconv_fwd(const void* g, const int32_t* lengths, const float* w, const float* bias, void* h, double* stats,
+                         int64_t B, int64_t N, int64_t d, int64_t ksize, sconf_stream_t stream);
+int sconf_brn_finalize(const double* stats, int64_t count, float* running_mean, float* running_std,
+                       int64_t* num_batches_tracked, const float* weight, const float* bias, float* coef, int64_t d,
+                       int training, float eps, float momentum, sconf_stream_t stream);
+int sconf_affine_silu_fwd(const void* h, const float* coef, void* y, int64_t M, int64_t d, sconf_stream_t stream);
+int sconf_convmod_bwd(const void* dy, const void* h, const void* g, const int32_t* lengths, const float* w,
+                      const float* brn_weight, const float* coef, double* red, float* bcoef, void* dg, float* dw,
+                      float* dbias, float* dbrn_weight, float* dbrn_bias, int64_t B, int64_t N, int64_t d, int64_t ksize,
+                      int training, float eps, sconf_stream_t stream);
+
+/* ConvSubsampling 'dw_striding' x8, channels-last (subsampling.py:276-321, 384-428). */
+int sconf_sub_conv0_fwd(const void* x, int x_dtype, const float* w, const float* bias, void* y, int64_t B, int64_t F,
+                        int64_t T, int64_t C, sconf_stream_t stream);
+int sconf_sub_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int64_t Ti, int64_t Fi,
+                         int64_t C, sconf_stream_t stream);
+int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void* pre_in, void* dpre_in, float* dw, float* dbias,
+                         int64_t B, int64_t Ti, int64_t Fi, int64_t C, sconf_stream_t stream);
+int sconf_sub_conv0_bwd(const void* dpre0, const void* x, int x_dtype, float* dw, float* dbias, int64_t B, int64_t F,
+                        int64_t T, int64_t C, sconf_stream_t stream);
+int sconf_sub_silu_transpose(int bwd, const void* pre, const void* ds, void* out, int64_t rows, int64_t F8, int64_t C,
+                             sconf_stream_t stream);
+
+/* CTC, torch.nn.CTCLoss(blank, reduction='sum') on the (N,B,C) view (exp/train.py:104,249); batch-major input.
+ * lpg/alpha/beta: f32 [B][N][2*Smax+1] workspaces; nll: f32 [B]; grad_out: f32 [B] or NULL. */
+int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
+                  const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll, int64_t B, int64_t N,
+                  int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
+int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const float* nll,
+                  const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths, const float* grad_out,
+                  float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
+
+/* Fused MADGRAD + global-norm clip over flat f32 buffers (lcasr/optim/madgrad.py:81-212, exp/train.py:46-61). */
+int sconf_sumsq(const float* g, int64_t n, double* out, sconf_stream_t stream);
+int sconf_madgrad_step(float* p, const float* g, float* grad_sum_sq, float* s, const float* x0, void* bf16_shadow,
+                       int64_t n, const double* sumsq, float max_norm, float grad_scale, float lr, float momentum,
+                       float eps, float weight_decay, int64_t k, sconf_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCONF_H */

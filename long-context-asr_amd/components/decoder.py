@@ -1,0 +1,36 @@
+"""ASRLinearSCDecoder (lcasr/components/decoder.py:6-32): ff Linear(d -> V+1), reprojection Linear(V+1 -> d), norm."""
+import torch.nn as nn
+
+from .. import functional as Fn
+from .normalisation import RMSNorm
+
+
+class ASRLinearSCDecoder(nn.Module):
+    def __init__(self, d_model, vocab_size, norm=False, norm_fn=RMSNorm, **kwargs):
+        super().__init__()
+        self.num_classes = vocab_size + 1                      # + blank
+        self.ff = nn.Linear(d_model, self.num_classes)
+        self.reprojection = nn.Linear(self.num_classes, d_model)
+        self.norm = norm_fn(d_model) if norm else nn.Identity()
+        self.has_norm = bool(norm)
+
+    def _np(self):
+        return self.norm.norm_params() if self.has_norm else (None, None)
+
+    def forward(self, x, logits=False, extra_norms=0):
+        """log_softmax(ff(norm(x)))  (decoder.py:22-26); extra_norms=1 applies the norm twice (legacy double norm)."""
+        shape = x.shape
+        nw, nb = self._np()
+        n_norms = (1 + extra_norms) if self.has_norm else 0
+        mode, eps = (self.norm.mode, self.norm.eps) if self.has_norm else ('layer_norm', 1e-5)
+        y = Fn.decoder_head(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, n_norms, mode, eps, logits)
+        return y.view(*shape[:-1], self.num_classes)
+
+    def self_condition(self, x):
+        """x + reprojection(softmax(ff(norm(x))))  (sconformer_xl.py:241-243)."""
+        shape = x.shape
+        nw, nb = self._np()
+        mode, eps = (self.norm.mode, self.norm.eps) if self.has_norm else ('layer_norm', 1e-5)
+        y = Fn.selfcond_block(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, self.reprojection.weight,
+                              self.reprojection.bias, self.has_norm, mode, eps)
+        return y.view(shape)

@@ -1,0 +1,31 @@
+"""FusedMLP (lcasr/components/fused_dense.py:425-498): Linear(d->4d) + GELU(tanh) + Linear(4d->d).
+
+Replaces fused_dense_cuda.linear_act_forward / bias_act_linear_dgrad_bgrad / linear_bias_wgrad with the HIP
+GEMM epilogues (csrc/gemm.hip).  fc1/fc2 are torch.nn.Linear parameter containers so that initialisation and
+state_dict keys are identical to the reference."""
+import torch.nn as nn
+
+from .. import functional as Fn
+
+
+class FusedMLP(nn.Module):
+    def __init__(self, in_features, hidden_features=None, out_features=None, bias1=True, bias2=True,
+                 activation='gelu_approx', return_residual=False, checkpoint_lvl=0, heuristic='auto', device=None, dtype=None):
+        assert checkpoint_lvl in [0, 1, 2]
+        if activation != 'gelu_approx':
+            raise NotImplementedError("only activation='gelu_approx' is used by SConformerXL")
+        if return_residual:
+            raise NotImplementedError('return_residual is not used by SConformerXL')
+        super().__init__()
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features * 4
+        self.activation, self.return_residual, self.checkpoint_lvl, self.heuristic = activation, return_residual, checkpoint_lvl, heuristic
+        self.fc1 = nn.Linear(in_features, hidden_features, bias=bias1, device=device, dtype=dtype)
+        self.fc2 = nn.Linear(hidden_features, out_features, bias=bias2, device=device, dtype=dtype)
+
+    def forward_prenorm(self, x, norm, residual, scale=1.0):
+        shape = x.shape
+        nw, nb = norm.norm_params()
+        y = Fn.ff_block(x.reshape(-1, shape[-1]), nw, nb, self.fc1.weight, self.fc2.weight, self.fc1.bias, self.fc2.bias,
+                        scale, norm.mode, norm.eps, self.checkpoint_lvl, residual)
+        return y.view(shape)

@@ -1,0 +1,501 @@
+// Flash-style bidirectional self-attention for gfx950, forward + backward, head_dim 32 or 128.
+// Replaces flash_attn_qkvpacked_func / flash_attn_varlen_qkvpacked_func + bert_padding un/pad
+// (attention.py:235-257, 527-535) and the CPU SDPA branch (attention.py:536-544):
+// non-causal softmax(QK^T/sqrt(D))V, optional key-padding via per-sample lengths (ragged batches
+// stay padded: no unpad/pad copies), optional sliding window (left,right) with flash-attn semantics.
+//
+// MI355X design
+//  * v_mfma_f32_32x32x16_bf16 everywhere; scores are computed TRANSPOSED (S^T = K Q^T) so the query
+//    index sits on the lane: running max / sum / LSE / delta are lane-local scalars and the f32
+//    score accumulators are, after a bf16 pack, directly the B operand of the next MFMA
+//    (O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS) — P never touches LDS.
+//  * The other operand of those products is read from the row-major LDS tile with the hardware
+//    transpose read ds_read_b64_tr_b16; ONE swizzled LDS image per tile serves both the row reads
+//    (ds_read_b128) and the transposed reads conflict-free.
+//  * K/V (or Q/dO) tiles are staged global -> registers -> LDS, issue-early / write-late, double
+//    buffered, one barrier per tile.
+//  * Backward = two kernels (dK/dV with keys resident per wave; dQ with queries resident per wave):
+//    no atomics, bitwise reproducible, at the price of recomputing S and dP once more.
+#include "common.h"
+
+namespace {
+
+struct AttnParams {
+    const bf16 *q, *k, *v;            // (B,N,H,D) views: element (b,n,h,d) at b*sb + n*sn + h*sh + d
+    bf16* o;
+    const bf16 *dout;                 // backward
+    bf16 *dq, *dk, *dv;
+    float* lse;                       // (B,H,N) natural-log LSE of the scaled scores
+    float* delta;                     // (B,H,N) rowsum(dO * O)
+    long q_sb, q_sn, q_sh, k_sb, k_sn, k_sh, v_sb, v_sn, v_sh, o_sb, o_sn, o_sh;
+    long do_sb, do_sn, do_sh, dq_sb, dq_sn, dq_sh, dk_sb, dk_sn, dk_sh, dv_sb, dv_sn, dv_sh;
+    const int* lengths;               // per-sample valid length (queries and keys), or null
+    int B, N, H;
+    int win_left, win_right;          // -1 = unbounded
+    float scale;                      // 1/sqrt(D)
+};
+
+template <int D> __device__ __forceinline__ int tile_off(int row, int ch) {
+    const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+    return row * (2 * D) + ((ch ^ swz) << 4);
+}
+
+// ---- staging of a [ROWS][D] bf16 tile ---------------------------------------------------------
+template <int D, int ROWS> struct Stage {
+    static constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = (CHUNKS + 255) / 256;
+    uint4 r[PER];
+    __device__ __forceinline__ void gload(const bf16* base, long sn, int row0, int nrows_valid, int tid) {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (c < CHUNKS) {
+                const int row = c / CPR, ch = c % CPR;
+                if (row0 + row < nrows_valid) v = *reinterpret_cast<const uint4*>(base + (long)(row0 + row) * sn + ch * 8);
+            }
+            r[i] = v;
+        }
+    }
+    __device__ __forceinline__ void lstore(char* s, int tid) const {
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const int c = tid + 256 * i;
+            if (c < CHUNKS) *reinterpret_cast<uint4*>(s + tile_off<D>(c / CPR, c % CPR)) = r[i];
+        }
+    }
+};
+
+// A operand, row form: A[row = rbase + lane&31][k = 16*st + 8*hh + j]
+template <int D> __device__ __forceinline__ bf16x8 frag_row(const char* s, int rbase, int st, int lane) {
+    return *reinterpret_cast<const bf16x8*>(s + tile_off<D>(rbase + (lane & 31), 2 * st + (lane >> 5)));
+}
+// A operand, transposed form: A[row = tile column cbase + lane&31][k-slot j] where slot j of lane half hh is
+// tile row  rb + 8*(j>>2) + 4*hh + (j&3)  — the k order of a packed 32x32 accumulator (B operand).
+template <int D> __device__ __forceinline__ bf16x8 frag_tr(const char* s, int rb, int cbase, int lane) {
+    const int i = lane & 15, q4 = i >> 2, p4 = i & 3, G = (lane >> 4) & 1, hh = lane >> 5;
+    const int row0 = rb + 4 * hh + q4, ch = (cbase >> 3) + 2 * G + (p4 >> 1), sub = (p4 & 1) * 8;
+    typedef __attribute__((address_space(3))) bf16x4* lds_p;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + tile_off<D>(row0, ch) + sub));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + tile_off<D>(row0 + 8, ch) + sub));
+    return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+// B operand straight from global: B[k = 16*st + 8*hh + j][col = lane&31] = X[row0 + lane&31][d]
+template <int D> __device__ __forceinline__ void load_bfrags(bf16x8 (&f)[D / 16], const bf16* base, long sn, int row0, int nvalid, int lane) {
+    const int r = row0 + (lane & 31);
+#pragma unroll
+    for (int st = 0; st < D / 16; ++st) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < nvalid) v = *reinterpret_cast<const uint4*>(base + (long)r * sn + 16 * st + 8 * (lane >> 5));
+        f[st] = __builtin_bit_cast(bf16x8, v);
+    }
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& a, int s2) {
+    bf16x8 p;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) p[j] = (bf16)a[8 * s2 + j];
+    return p;
+}
+__device__ __forceinline__ int acc_row(int r, int hh) { return (r & 3) + 8 * (r >> 2) + 4 * hh; }
+
+// store a transposed accumulator set X^T[d][row] (d over D/32 blocks) as X[row][d] bf16, scaled
+template <int D> __device__ __forceinline__ void store_t(const f32x16 (&acc)[D / 32], bf16* dst_row, float sc, int hh) {
+#pragma unroll
+    for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[db][4 * r4 + e] * sc;
+            store4(dst_row + db * 32 + 8 * r4 + 4 * hh, v);
+        }
+}
+
+// =============================================================================================
+// forward: grid (ceil(N/128), H, B), 4 waves x 32 query rows, 64-key tiles
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * 2 * D;                     // bytes of one 64-row tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const int qi = q0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[D / 16];
+    load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+
+    const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
+    const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 128 + p.win_right);
+    const int t_lo = kv_lo / 64, t_hi = (kv_hi + 63) / 64;
+    const bool windowed = p.win_left >= 0 || p.win_right >= 0;
+
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    Stage<D, 64> sk, sv;
+    if (t_lo < t_hi) {
+        sk.gload(kp, p.k_sn, t_lo * 64, p.N, tid); sv.gload(vp, p.v_sn, t_lo * 64, p.N, tid);
+        sk.lstore(smem, tid); sv.lstore(smem + TB, tid);
+    }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sK = smem + cur * 2 * TB;
+        const char* sV = sK + TB;
+        if (t + 1 < t_hi) { sk.gload(kp, p.k_sn, (t + 1) * 64, p.N, tid); sv.gload(vp, p.v_sn, (t + 1) * 64, p.N, tid); }
+        const int kv0 = t * 64;
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kt * 32, st, lane), qf[st], s[kt], 0, 0, 0);
+        }
+        if (kv0 + 64 > kv_hi || windowed) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + acc_row(r, hh);
+                    bool ok = key < len;
+                    if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
+                    if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
+                    if (!ok) s[kt][r] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float mu = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = __builtin_amdgcn_exp2f((m - mu) * c);
+        const float mc = mu * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] * c - mc); s[kt][r] = e; rs += e; }
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { pf[kt][0] = pack8(s[kt], 0); pf[kt][1] = pack8(s[kt], 1); }
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sV, kt * 32 + 16 * s2, db * 32, lane), pf[kt][s2], o[db], 0, 0, 0);
+        if (t + 1 < t_hi) {
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            sk.lstore(dK, tid); sv.lstore(dK + TB, tid);
+        }
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    if (qi < p.N) {
+        const bool live = qi < len && lt > 0.f;
+        const float inv = live ? 1.f / lt : 0.f;
+        store_t<D>(o, p.o + b * p.o_sb + (long)qi * p.o_sn + h * p.o_sh, inv, hh);
+        if (hh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.N + qi] = live ? (m * c + __log2f(lt)) * 0.6931471805599453f : INFINITY;
+    }
+}
+
+// delta[b][h][n] = sum_d dO * O
+template <int D>
+__global__ void attn_delta_kernel(const AttnParams p) {
+    constexpr int LPR = D / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long rows = (long)p.B * p.N * p.H;
+    const long row = idx / LPR;
+    const int ch = (int)(idx % LPR);
+    float acc = 0.f;
+    long bb = 0, n = 0, hd = 0;
+    if (row < rows) {
+        hd = row % p.H; n = (row / p.H) % p.N; bb = row / ((long)p.H * p.N);
+        float a[8], g[8];
+        load8(p.o + bb * p.o_sb + n * p.o_sn + hd * p.o_sh + ch * 8, a);
+        load8(p.dout + bb * p.do_sb + n * p.do_sn + hd * p.do_sh + ch * 8, g);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc += a[e] * g[e];
+    }
+#pragma unroll
+    for (int o = LPR / 2; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (row < rows && ch == 0) p.delta[(bb * p.H + hd) * p.N + n] = acc;
+}
+
+// =============================================================================================
+// backward dK/dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps 32-row query tiles
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 32 * 2 * D;                     // Q tile / dO tile bytes (32 rows)
+    constexpr int SB = 2 * TB + 256;                   // one stage: Q | dO | lse2[32] | delta[32]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128, k0 = kb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
+    const float* lsep = p.lse + ((long)b * p.H + h) * p.N;
+    const float* delp = p.delta + ((long)b * p.H + h) * p.N;
+    const int key = k0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+
+    bf16x8 kf[D / 16], vf[D / 16];
+    load_bfrags<D>(kf, kp, p.k_sn, k0, p.N, lane);
+    load_bfrags<D>(vf, vp, p.v_sn, k0, p.N, lane);
+
+    // queries that can see this block's keys: key in [q-left, q+right]  <=>  q in [key-right, key+left]
+    const int q_lo = p.win_right < 0 ? 0 : max(0, kb0 - p.win_right);
+    const int q_hi = min(len, p.win_left < 0 ? len : kb0 + 128 + p.win_left);
+    const int t_lo = q_lo / 32, t_hi = (kb0 < len) ? (q_hi + 31) / 32 : t_lo;
+
+    f32x16 dkt[D / 32], dvt[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
+
+    Stage<D, 32> sq, sg;
+    float st_l = 0.f, st_d = 0.f;
+    auto gload_stats = [&](int q0) {
+        if (tid < 32) { const int q = q0 + tid; st_l = (q < len) ? lsep[q] * 1.4426950408889634f : INFINITY; st_d = (q < len) ? delp[q] : 0.f; }
+    };
+    auto lstore_stats = [&](char* s) {
+        if (tid < 32) { reinterpret_cast<float*>(s + 2 * TB)[tid] = st_l; reinterpret_cast<float*>(s + 2 * TB + 128)[tid] = st_d; }
+    };
+    if (t_lo < t_hi) {
+        sq.gload(qp, p.q_sn, t_lo * 32, p.N, tid); sg.gload(gp, p.do_sn, t_lo * 32, p.N, tid); gload_stats(t_lo * 32);
+        sq.lstore(smem, tid); sg.lstore(smem + TB, tid); lstore_stats(smem);
+    }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sQ = smem + cur * SB;
+        const char* sG = sQ + TB;
+        const float* sL = reinterpret_cast<const float*>(sQ + 2 * TB);
+        const float* sD = sL + 32;
+        if (t + 1 < t_hi) { sq.gload(qp, p.q_sn, (t + 1) * 32, p.N, tid); sg.gload(gp, p.do_sn, (t + 1) * 32, p.N, tid); gload_stats((t + 1) * 32); }
+        const int q0 = t * 32;
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int st = 0; st < D / 16; ++st) {
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, 0, st, lane), kf[st], s, 0, 0, 0);     // S[q][key]
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sG, 0, st, lane), vf[st], dp, 0, 0, 0);   // dP[q][key]
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int qr = acc_row(r, hh), q = q0 + qr;
+            bool ok = key < len;
+            if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
+            if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
+            const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - sL[qr]) : 0.f;   // lse2 = +inf for q >= len
+            s[r] = pr;
+            dp[r] = pr * (dp[r] - sD[qr]);
+        }
+        const bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db) {
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, 0, db * 32, lane), pb0, dvt[db], 0, 0, 0);
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, 16, db * 32, lane), pb1, dvt[db], 0, 0, 0);
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, 0, db * 32, lane), db0, dkt[db], 0, 0, 0);
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, 16, db * 32, lane), db1, dkt[db], 0, 0, 0);
+        }
+        if (t + 1 < t_hi) {
+            char* dS = smem + (cur ^ 1) * SB;
+            sq.lstore(dS, tid); sg.lstore(dS + TB, tid); lstore_stats(dS);
+        }
+        __syncthreads();
+    }
+    if (key < p.N) {
+        store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, hh);
+        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, hh);
+    }
+}
+
+// =============================================================================================
+// backward dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps 64-key tiles
+// =============================================================================================
+template <int D>
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = 64 * 2 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
+    const int qi = q0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+    const float lse2 = (qi < len) ? p.lse[((long)b * p.H + h) * p.N + qi] * 1.4426950408889634f : INFINITY;
+    const float dlt = (qi < len) ? p.delta[((long)b * p.H + h) * p.N + qi] : 0.f;
+
+    bf16x8 qf[D / 16], gf[D / 16];
+    load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+    load_bfrags<D>(gf, gp, p.do_sn, q0, p.N, lane);
+
+    const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
+    const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 128 + p.win_right);
+    const int t_lo = kv_lo / 64, t_hi = (qb0 < len) ? (kv_hi + 63) / 64 : t_lo;
+
+    f32x16 dqt[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
+
+    Stage<D, 64> sk, sv;
+    if (t_lo < t_hi) {
+        sk.gload(kp, p.k_sn, t_lo * 64, p.N, tid); sv.gload(vp, p.v_sn, t_lo * 64, p.N, tid);
+        sk.lstore(smem, tid); sv.lstore(smem + TB, tid);
+    }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sK = smem + cur * 2 * TB;
+        const char* sV = sK + TB;
+        if (t + 1 < t_hi) { sk.gload(kp, p.k_sn, (t + 1) * 64, p.N, tid); sv.gload(vp, p.v_sn, (t + 1) * 64, p.N, tid); }
+        const int kv0 = t * 64;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kt * 32, st, lane), qf[st], s, 0, 0, 0);    // S^T[key][q]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, kt * 32, st, lane), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kv0 + kt * 32 + acc_row(r, hh);
+                bool ok = key < len;
+                if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
+                if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
+                const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
+                dp[r] = pr * (dp[r] - dlt);
+            }
+            const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, kt * 32, db * 32, lane), d0, dqt[db], 0, 0, 0);
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, kt * 32 + 16, db * 32, lane), d1, dqt[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < t_hi) {
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            sk.lstore(dK, tid); sv.lstore(dK + TB, tid);
+        }
+        __syncthreads();
+    }
+    if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+}
+
+void set_lds_attrs() {
+    static bool done = false;
+    if (done) return;
+    (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 32 * 256 + 256));
+    done = true;
+}
+
+int check_common(const char* fn, int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* strides, int nstr) {
+    if (!(D == 32 || D == 128)) return sconf_set_error("%s: head_dim %ld not supported (32 or 128)", fn, (long)D);
+    if (B <= 0 || N <= 0 || H <= 0) return sconf_set_error("%s: empty problem", fn);
+    if (B > 65535 || H > 65535) return sconf_set_error("%s: B and H must be <= 65535", fn);
+    for (int i = 0; i < nstr; ++i) if (strides[i] % 8 != 0) return sconf_set_error("%s: strides must be multiples of 8 elements", fn);
+    return 0;
+}
+
+}  // namespace
+
+// q,k,v,o: bf16 (B,N,H,D) strided views (stride_b, stride_n, stride_h in elements; d contiguous).
+// lengths: int32 [B] or null — keys >= length are masked and query rows >= length are written as zeros
+// (attention.py:546-547).  lse: f32 (B,H,N) or null.  window -1 = unbounded.
+SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* lengths,
+                             int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* q_strides, const int64_t* k_strides,
+                             const int64_t* v_strides, const int64_t* o_strides, int win_left, int win_right, float scale,
+                             hipStream_t stream) {
+    int64_t all[12];
+    for (int i = 0; i < 3; ++i) { all[i] = q_strides[i]; all[3 + i] = k_strides[i]; all[6 + i] = v_strides[i]; all[9 + i] = o_strides[i]; }
+    if (check_common("sconf_attn_fwd", B, N, H, D, all, 12)) return 1;
+    AttnParams p = {};
+    p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)o; p.lse = lse; p.lengths = lengths;
+    p.q_sb = q_strides[0]; p.q_sn = q_strides[1]; p.q_sh = q_strides[2];
+    p.k_sb = k_strides[0]; p.k_sn = k_strides[1]; p.k_sh = k_strides[2];
+    p.v_sb = v_strides[0]; p.v_sn = v_strides[1]; p.v_sh = v_strides[2];
+    p.o_sb = o_strides[0]; p.o_sn = o_strides[1]; p.o_sh = o_strides[2];
+    p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
+    dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
+    set_lds_attrs();
+    if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
+    else          hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
+    SCONF_LAUNCH_OK("sconf_attn_fwd");
+    return 0;
+}
+
+// Backward.  delta: f32 (B,H,N) scratch.  dq/dk/dv: bf16 strided like q/k/v.
+SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                             float* delta, void* dq, void* dk, void* dv, const int32_t* lengths,
+                             int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* q_strides, const int64_t* k_strides,
+                             const int64_t* v_strides, const int64_t* o_strides, const int64_t* do_strides,
+                             const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
+                             int win_left, int win_right, float scale, hipStream_t stream) {
+    int64_t all[24];
+    const int64_t* ss[8] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
+    for (int j = 0; j < 8; ++j) for (int i = 0; i < 3; ++i) all[3 * j + i] = ss[j][i];
+    if (check_common("sconf_attn_bwd", B, N, H, D, all, 24)) return 1;
+    AttnParams p = {};
+    p.q = (const bf16*)q; p.k = (const bf16*)k; p.v = (const bf16*)v; p.o = (bf16*)const_cast<void*>(o); p.dout = (const bf16*)dout;
+    p.lse = const_cast<float*>(lse); p.delta = delta; p.dq = (bf16*)dq; p.dk = (bf16*)dk; p.dv = (bf16*)dv; p.lengths = lengths;
+    p.q_sb = q_strides[0]; p.q_sn = q_strides[1]; p.q_sh = q_strides[2];
+    p.k_sb = k_strides[0]; p.k_sn = k_strides[1]; p.k_sh = k_strides[2];
+    p.v_sb = v_strides[0]; p.v_sn = v_strides[1]; p.v_sh = v_strides[2];
+    p.o_sb = o_strides[0]; p.o_sn = o_strides[1]; p.o_sh = o_strides[2];
+    p.do_sb = do_strides[0]; p.do_sn = do_strides[1]; p.do_sh = do_strides[2];
+    p.dq_sb = dq_strides[0]; p.dq_sn = dq_strides[1]; p.dq_sh = dq_strides[2];
+    p.dk_sb = dk_strides[0]; p.dk_sn = dk_strides[1]; p.dk_sh = dk_strides[2];
+    p.dv_sb = dv_strides[0]; p.dv_sn = dv_strides[1]; p.dv_sh = dv_strides[2];
+    p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
+    const long rows = B * N * H;
+    set_lds_attrs();
+    dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
+    if (D == 128) {
+        hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256), stream, p);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
+    } else {
+        hipLaunchKernelGGL((attn_delta_kernel<32>), dim3(cdiv(rows * 4, 256)), dim3(256), 0, stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<32>), grid, block, 2 * (2 * 32 * 64 + 256), stream, p);
+        hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
+    }
+    SCONF_LAUNCH_OK("sconf_attn_bwd");
+    return 0;
+}

@@ -1,0 +1,196 @@
+// CTC loss (sum reduction, arbitrary blank) forward + backward in log space, replacing
+// torch.nn.CTCLoss(blank=num_classes-1, reduction='sum') on the (N,B,C) view of final_posteriors
+// (exp/train.py:104,249).  Batch-major (B,N,C) f32 log-probs are consumed directly.
+//
+// Structure (the recursion is serial in time with only B-way batch parallelism):
+//   1. gather   lpg[b][t][s] = lp[b][t][l'_s]        fully parallel; makes the serial pass read contiguous rows
+//   2. alpha/beta  one workgroup per (sample, direction): 2B workgroups run concurrently; the lattice row lives
+//                  in LDS (double-buffered, one barrier per step); lpg rows are prefetched 4 steps ahead into
+//                  registers so the serial chain never waits on HBM.  beta is alpha on the mirrored lattice.
+//   3. grad     one workgroup per (b,t) row: occupancy scattered into an LDS histogram over classes, then
+//               grad = g * (exp(lp) - occupancy)   [ATen convention; zero for t >= input_length].
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lse3(float a, float b, float c) {
+    const float m = fmaxf(a, fmaxf(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+}
+
+__global__ void ctc_gather_kernel(const float* __restrict__ lp, const int* __restrict__ targets, const int* __restrict__ in_len,
+                                  const int* __restrict__ tg_len, float* __restrict__ lpg, int B, int N, int C, int Smax,
+                                  int Lmax, int blank) {
+    const long total = (long)B * N * Lmax;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int s = (int)(idx % Lmax);
+        const long bt = idx / Lmax;
+        const int t = (int)(bt % N), b = (int)(bt / N);
+        float v = 0.f;
+        if (t < in_len[b] && s < 2 * tg_len[b] + 1) {
+            const int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
+            v = lp[bt * C + lab];
+        }
+        lpg[idx] = v;
+    }
+}
+
+// One workgroup per (sample, direction).  MAXS = max lattice states per thread.
+template <int MAXS>
+__global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ targets,
+                                                             const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                             float* __restrict__ alpha, float* __restrict__ beta,
+                                                             float* __restrict__ nll, int B, int N, int Smax, int Lmax, int blank) {
+    extern __shared__ float lat[];                      // [2][Lmax + 2], two leading -inf guard cells per row
+    const int b = blockIdx.x % B;
+    const bool is_beta = blockIdx.x >= B;
+    const int T = in_len[b], S = tg_len[b], L = 2 * S + 1;
+    float* out = (is_beta ? beta : alpha) + (long)b * N * Lmax;
+    const float* lg = lpg + (long)b * N * Lmax;
+    const int nt = blockDim.x, tid = threadIdx.x;
+    const int W = Lmax + 2;
+    if (T <= 0) { if (!is_beta && tid == 0) nll[b] = INFINITY; return; }
+
+    // per-state constants in MIRRORED coordinates sp (beta walks the reversed lattice)
+    bool skip_ok[MAXS];
+#pragma unroll
+    for (int k = 0; k < MAXS; ++k) {
+        const int sp = tid + k * nt;
+        skip_ok[k] = false;
+        if (sp < L && sp >= 2) {
+            const int s = is_beta ? L - 1 - sp : sp;
+            if (s & 1) {
+                const int s2 = is_beta ? s + 2 : s - 2;
+                skip_ok[k] = targets[(long)b * Smax + (s >> 1)] != targets[(long)b * Smax + (s2 >> 1)];
+            }
+        }
+    }
+    for (int i = tid; i < 2 * W; i += nt) lat[i] = -INFINITY;
+    __syncthreads();
+
+    float pf[4][MAXS], nx[4][MAXS];
+    auto load_group = [&](float (&dst)[4][MAXS], int i0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j;
+            const int t = is_beta ? T - 1 - i : i;
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k) {
+                const int sp = tid + k * nt;
+                const int s = is_beta ? L - 1 - sp : sp;
+                dst[j][k] = (i < T && sp < L) ? lg[(long)t * Lmax + s] : 0.f;
+            }
+        }
+    };
+    load_group(pf, 0);
+    for (int i0 = 0; i0 < T; i0 += 4) {
+        load_group(nx, i0 + 4);                          // prefetch the next 4 time steps
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = i0 + j;
+            if (i < T) {                                  // uniform across the workgroup
+                const int t = is_beta ? T - 1 - i : i;
+                float* cur = lat + (i & 1) * W + 2;
+                const float* prev = lat + ((i & 1) ^ 1) * W + 2;
+#pragma unroll
+                for (int k = 0; k < MAXS; ++k) {
+                    const int sp = tid + k * nt;
+                    if (sp < L) {
+                        float v;
+                        if (i == 0) v = (sp < 2) ? pf[j][k] : -INFINITY;
+                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : -INFINITY) + pf[j][k];
+                        cur[sp] = v;
+                        out[(long)t * Lmax + (is_beta ? L - 1 - sp : sp)] = v;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k) pf[j][k] = nx[j][k];
+    }
+    if (!is_beta && tid == 0) {
+        const float* last = lat + ((T - 1) & 1) * W + 2;
+        nll[b] = -lse3(last[L - 1], L > 1 ? last[L - 2] : -INFINITY, -INFINITY);
+    }
+}
+
+__global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ lpg,
+                                                       const float* __restrict__ alpha, const float* __restrict__ beta,
+                                                       const float* __restrict__ nll, const int* __restrict__ targets,
+                                                       const int* __restrict__ in_len, const int* __restrict__ tg_len,
+                                                       const float* __restrict__ grad_out, float* __restrict__ grad,
+                                                       int N, int C, int Smax, int Lmax, int blank) {
+    extern __shared__ float occ[];                      // [C]
+    const long bt = blockIdx.x;
+    const int b = (int)(bt / N), t = (int)(bt % N);
+    float* gr = grad + bt * C;
+    if (t >= in_len[b]) {
+        for (int c = threadIdx.x * 4; c < C; c += 1024) { float z[4] = {0.f, 0.f, 0.f, 0.f}; store4(gr + c, z); }
+        return;
+    }
+    for (int c = threadIdx.x; c < C; c += 256) occ[c] = 0.f;
+    __syncthreads();
+    const int L = 2 * tg_len[b] + 1;
+    const float nl = nll[b];
+    const long base = bt * Lmax;
+    for (int s = threadIdx.x; s < L; s += 256) {
+        const int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
+        atomicAdd(&occ[lab], __expf(alpha[base + s] + beta[base + s] + nl - lpg[base + s]));
+    }
+    __syncthreads();
+    const float g = grad_out ? grad_out[b] : 1.f;          // per-sample upstream gradient
+    for (int c = threadIdx.x * 4; c < C; c += 1024) {
+        float v[4]; load4(lp + bt * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g * (__expf(v[e]) - occ[c + e]);
+        store4(gr + c, v);
+    }
+}
+
+}  // namespace
+
+// Workspace contract: lpg, alpha, beta are f32 [B][N][Lmax] with Lmax = 2*Smax+1 (caller-allocated).
+// targets int32 [B][Smax]; input_lengths / target_lengths int32 [B].  nll f32 [B] (loss = sum).
+SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
+                            const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
+                            int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
+    if (B == 0) return 0;
+    const int Lmax = (int)(2 * Smax + 1);
+    SCONF_REQUIRE(blank >= 0 && blank < C, "sconf_ctc_fwd: blank %d out of range", blank);
+    SCONF_REQUIRE((long)(Lmax + 2) * 8 <= 160 * 1024, "sconf_ctc_fwd: lattice of %d states does not fit LDS", Lmax);
+    const long total = B * N * Lmax;
+    hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, stream,
+                       log_probs, targets, input_lengths, target_lengths, lpg, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
+    const int nt = Lmax <= 256 ? 256 : (Lmax <= 2048 ? 512 : 1024);
+    const int spt = cdiv(Lmax, nt);
+    const size_t sh = (size_t)2 * (Lmax + 2) * sizeof(float);
+    SCONF_REQUIRE(spt <= 16, "sconf_ctc_fwd: target too long (%ld labels)", (long)Smax);
+#define L(MS) do { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((ctc_alphabeta_kernel<MS>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
+                           target_lengths, alpha, beta, nll, (int)B, (int)N, (int)Smax, Lmax, blank); } while (0)
+    if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
+#undef L
+    SCONF_LAUNCH_OK("sconf_ctc_fwd");
+    return 0;
+}
+
+// grad (B,N,C) f32 = grad_out[b] * (exp(lp) - occupancy), zero for t >= input_length (ATen ctc_loss backward).
+// grad_out: f32 [B] (per-sample upstream gradient of the nll vector) or null (= 1).
+SCONF_API int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const float* nll,
+                            const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
+                            const float* grad_out, float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank,
+                            hipStream_t stream) {
+    if (B * N == 0) return 0;
+    SCONF_REQUIRE(C % 4 == 0, "sconf_ctc_bwd: C must be a multiple of 4");
+    SCONF_REQUIRE(C * 4 <= 64 * 1024, "sconf_ctc_bwd: %ld classes do not fit LDS", (long)C);
+    const int Lmax = (int)(2 * Smax + 1);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)(B * N)), dim3(256), (size_t)C * 4, stream, log_probs, lpg, alpha, beta, nll,
+                       targets, input_lengths, target_lengths, grad_out, grad, (int)N, (int)C, (int)Smax, Lmax, blank);
+    SCONF_LAUNCH_OK("sconf_ctc_bwd");
+    return 0;
+}

@@ -1,0 +1,280 @@
+// HBM-bound helpers of the SConformerXL path: casts, qkv de-interleave + rotary, row softmax /
+// log-softmax (forward + backward), bias-gradient column sums, padded-row masking.
+#include "common.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) { float v[8]; load8(s + i, v); store8(d + i, v); }
+    if (i < n) for (long j = i; j < n && j < i + 8; ++j) d[j] = (bf16)s[j];
+}
+
+__global__ void cast_bf16_f32_kernel(const bf16* __restrict__ s, float* __restrict__ d, long n) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    const long stride = (long)gridDim.x * blockDim.x * 8;
+    for (; i + 8 <= n; i += stride) { float v[8]; load8(s + i, v); store8(d + i, v); }
+    if (i < n) for (long j = i; j < n && j < i + 8; ++j) d[j] = (float)s[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+// qkv de-interleave + NeoX rotary.  Reference layout of the qkv projection output is
+// "b n (h d qkv)" (attention.py:485): column (h*D + d)*3 + {0:q, 1:k, 2:v}.  One thread handles
+// 8 rotary pairs (d = i..i+7 and d + D/2) of one (row, head): 2 x 48 contiguous input bytes,
+// 16-B output stores.  cos/sin: (N, D/2) f32 tables built exactly like rotary_emb.py:44-57.
+template <bool BWD>
+__global__ void rotary_qkv_kernel(bf16* __restrict__ qkv, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                  bf16* __restrict__ q, bf16* __restrict__ k, bf16* __restrict__ v,
+                                  long M, int N, int H, int D, int use_rot) {
+    const int half = D / 2, gpr = half / 8;                     // groups of 8 pairs per (row, head)
+    const long total = M * H * gpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int gi = (int)(idx % gpr);
+        const int h = (int)((idx / gpr) % H);
+        const long m = idx / ((long)gpr * H);
+        const int n = (int)(m % N);
+        const int i0 = gi * 8;
+        bf16* src1 = qkv + (m * H * D + (long)h * D + i0) * 3;         // 24 contiguous bf16: (q,k,v) x 8 for d = i0..
+        bf16* src2 = src1 + (long)half * 3;                              // same for d + D/2
+        const long o1 = (m * H + h) * D + i0, o2 = o1 + half;
+        float c[8], s[8];
+        if (use_rot) { load8(cosT + (long)n * half + i0, c); load8(sinT + (long)n * half + i0, s); }
+        else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { c[e] = 1.f; s[e] = 0.f; }
+        }
+        if (!BWD) {
+            float a[24], b[24];
+            load8(src1, *(float(*)[8])&a[0]); load8(src1 + 8, *(float(*)[8])&a[8]); load8(src1 + 16, *(float(*)[8])&a[16]);
+            load8(src2, *(float(*)[8])&b[0]); load8(src2 + 8, *(float(*)[8])&b[8]); load8(src2 + 16, *(float(*)[8])&b[16]);
+            float q1[8], q2[8], k1[8], k2[8], v1[8], v2[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float qa = a[3 * e], ka = a[3 * e + 1], qb = b[3 * e], kb = b[3 * e + 1];
+                q1[e] = qa * c[e] - qb * s[e]; q2[e] = qb * c[e] + qa * s[e];   // x*cos + rotate_half(x)*sin
+                k1[e] = ka * c[e] - kb * s[e]; k2[e] = kb * c[e] + ka * s[e];
+                v1[e] = a[3 * e + 2]; v2[e] = b[3 * e + 2];
+            }
+            store8(q + o1, q1); store8(q + o2, q2); store8(k + o1, k1); store8(k + o2, k2);
+            store8(v + o1, v1); store8(v + o2, v2);
+        } else {
+            float q1[8], q2[8], k1[8], k2[8], v1[8], v2[8];
+            load8(q + o1, q1); load8(q + o2, q2); load8(k + o1, k1); load8(k + o2, k2); load8(v + o1, v1); load8(v + o2, v2);
+            float a[24], b[24];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {                                 // transpose of the rotation
+                a[3 * e] = q1[e] * c[e] + q2[e] * s[e];     b[3 * e] = q2[e] * c[e] - q1[e] * s[e];
+                a[3 * e + 1] = k1[e] * c[e] + k2[e] * s[e]; b[3 * e + 1] = k2[e] * c[e] - k1[e] * s[e];
+                a[3 * e + 2] = v1[e];                        b[3 * e + 2] = v2[e];
+            }
+            store8(src1, *(float(*)[8])&a[0]); store8(src1 + 8, *(float(*)[8])&a[8]); store8(src1 + 16, *(float(*)[8])&a[16]);
+            store8(src2, *(float(*)[8])&b[0]); store8(src2 + 8, *(float(*)[8])&b[8]); store8(src2 + 16, *(float(*)[8])&b[16]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row softmax family over C <= 8192 classes, one 256-thread block per row, row kept in registers.
+constexpr int SM_IT = 8;
+
+// MODE 0: softmax -> TO;  MODE 1: log_softmax -> TO
+template <typename TI, typename TO, int MODE>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, int C) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    const TI* xr = x + row * C;
+    float v[SM_IT][4];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+        const int c = it * 1024 + threadIdx.x * 4;
+        if (c < C) { load4(xr + c, v[it]); mx = fmaxf(mx, fmaxf(fmaxf(v[it][0], v[it][1]), fmaxf(v[it][2], v[it][3]))); }
+    }
+    mx = block_max(mx, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+        const int c = it * 1024 + threadIdx.x * 4;
+        if (c < C) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[it][e] -= mx; s += __expf(v[it][e]); }
+        }
+    }
+    s = block_sum(s, sh);
+    const float inv = 1.f / s, ls = __logf(s);
+    TO* yr = y + row * C;
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+        const int c = it * 1024 + threadIdx.x * 4;
+        if (c < C) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (MODE == 0) ? __expf(v[it][e]) * inv : v[it][e] - ls;
+            store4(yr + c, o);
+        }
+    }
+}
+
+// MODE 0: softmax bwd   dx = y * (dy - sum(dy*y))          (y = probabilities)
+// MODE 1: log_softmax bwd dx = dy - exp(y) * sum(dy)         (y = log-probabilities)
+template <typename TY, typename TG, typename TO, int MODE>
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__ y, const TG* __restrict__ dy,
+                                                          TO* __restrict__ dx, int C) {
+    __shared__ float sh[16];
+    const long row = blockIdx.x;
+    float yv[SM_IT][4], gv[SM_IT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+        const int c = it * 1024 + threadIdx.x * 4;
+        if (c < C) {
+            load4(y + row * C + c, yv[it]); load4(dy + row * C + c, gv[it]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s += (MODE == 0) ? gv[it][e] * yv[it][e] : gv[it][e];
+        }
+    }
+    s = block_sum(s, sh);
+#pragma unroll
+    for (int it = 0; it < SM_IT; ++it) {
+        const int c = it * 1024 + threadIdx.x * 4;
+        if (c < C) {
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = (MODE == 0) ? yv[it][e] * (gv[it][e] - s) : gv[it][e] - __expf(yv[it][e]) * s;
+            store4(dx + row * C + c, o);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// out[n] += sum_m x[m][n]   (bias gradients).  Block = 256 threads = 64 column-quads x 4 row lanes.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ld,
+                                                     int rows_per_block) {
+    __shared__ float sh[4][256];
+    const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cq * 4;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(M, r0 + rows_per_block);
+    float a[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < N) {
+        for (long r = r0 + rl; r < r1; r += 4) {
+            float v[4]; load4(x + r * ld + c, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sh[rl][cq * 4 + e] = a[e];
+    __syncthreads();
+    const int cc = blockIdx.x * 256 + threadIdx.x;
+    if (cc < N) atomicAdd(out + cc, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+}
+
+// Zero rows n >= len[b] of x[B][N][d] in place (attention.py:511,546-547; convolution.py:109-110).
+template <typename T>
+__global__ void mask_rows_kernel(T* __restrict__ x, const int* __restrict__ len, int B, int N, int d) {
+    const long total = (long)B * N * (d / 4);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long row = idx / (d / 4);
+        const int b = (int)(row / N), n = (int)(row % N);
+        if (n >= len[b]) { float z[4] = {0.f, 0.f, 0.f, 0.f}; store4(x + idx * 4, z); }
+    }
+}
+
+}  // namespace
+
+SCONF_API int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, hipStream_t stream) {
+    if (n == 0) return 0;
+    SCONF_REQUIRE(src_dtype != dst_dtype, "sconf_cast: same dtype");
+    const int blocks = (int)std::min<long>(cdiv(n, 256 * 8), 4096);
+    if (src_dtype == SCONF_F32) hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)src, (bf16*)dst, (long)n);
+    else hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)src, (float*)dst, (long)n);
+    SCONF_LAUNCH_OK("sconf_cast");
+    return 0;
+}
+
+// Replaces the rearrange "b n (h d qkv) -> qkv b n h d" + apply_rotary_pos_emb (attention.py:485,498-507,
+// rotary_emb.py:61-73).  bwd != 0 runs the transpose: (dq,dk,dv) -> dqkv (written into `qkv`).
+SCONF_API int sconf_rotary_qkv(int bwd, void* qkv, const float* cos_tab, const float* sin_tab, void* q, void* k, void* v,
+                               int64_t B, int64_t N, int64_t H, int64_t D, int use_rotary, hipStream_t stream) {
+    SCONF_REQUIRE(D % 16 == 0, "sconf_rotary_qkv: head_dim %ld must be a multiple of 16", (long)D);
+    const long M = B * N;
+    if (M == 0) return 0;
+    const long total = M * H * (D / 16);
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 8192);
+    if (!bwd) hipLaunchKernelGGL((rotary_qkv_kernel<false>), dim3(blocks), dim3(256), 0, stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)q, (bf16*)k, (bf16*)v, M, (int)N, (int)H, (int)D, use_rotary);
+    else      hipLaunchKernelGGL((rotary_qkv_kernel<true>), dim3(blocks), dim3(256), 0, stream, (bf16*)qkv, cos_tab, sin_tab, (bf16*)q, (bf16*)k, (bf16*)v, M, (int)N, (int)H, (int)D, use_rotary);
+    SCONF_LAUNCH_OK("sconf_rotary_qkv");
+    return 0;
+}
+
+// mode 0 softmax (sconformer_xl.py:242), mode 1 log_softmax (decoder.py:25).
+SCONF_API int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, int y_dtype, int64_t M, int64_t C, hipStream_t stream) {
+    SCONF_REQUIRE(C % 4 == 0 && C <= SM_IT * 1024 && C > 0, "sconf_softmax_fwd: C=%ld must be a multiple of 4 and <= 8192", (long)C);
+    if (M == 0) return 0;
+    dim3 g((unsigned)M), b(256);
+#define L(TI, TO, MD) hipLaunchKernelGGL((softmax_fwd_kernel<TI, TO, MD>), g, b, 0, stream, (const TI*)x, (TO*)y, (int)C)
+    if (mode == 0) {
+        if (x_dtype == SCONF_BF16 && y_dtype == SCONF_BF16) L(bf16, bf16, 0);
+        else if (x_dtype == SCONF_F32 && y_dtype == SCONF_BF16) L(float, bf16, 0);
+        else if (x_dtype == SCONF_F32 && y_dtype == SCONF_F32) L(float, float, 0);
+        else L(bf16, float, 0);
+    } else {
+        if (x_dtype == SCONF_BF16 && y_dtype == SCONF_BF16) L(bf16, bf16, 1);
+        else if (x_dtype == SCONF_F32 && y_dtype == SCONF_BF16) L(float, bf16, 1);
+        else if (x_dtype == SCONF_F32 && y_dtype == SCONF_F32) L(float, float, 1);
+        else L(bf16, float, 1);
+    }
+#undef L
+    SCONF_LAUNCH_OK("sconf_softmax_fwd");
+    return 0;
+}
+
+SCONF_API int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype,
+                                int64_t M, int64_t C, hipStream_t stream) {
+    SCONF_REQUIRE(C % 4 == 0 && C <= SM_IT * 1024 && C > 0, "sconf_softmax_bwd: C=%ld must be a multiple of 4 and <= 8192", (long)C);
+    SCONF_REQUIRE(dx_dtype == SCONF_BF16 || dx_dtype == SCONF_F32, "sconf_softmax_bwd: bad dx dtype");
+    if (M == 0) return 0;
+    dim3 g((unsigned)M), b(256);
+#define L(TY, TG, TO, MD) hipLaunchKernelGGL((softmax_bwd_kernel<TY, TG, TO, MD>), g, b, 0, stream, (const TY*)y, (const TG*)dy, (TO*)dx, (int)C)
+#define D3(MD) \
+    if (y_dtype == SCONF_BF16 && dy_dtype == SCONF_BF16) { if (dx_dtype == SCONF_BF16) L(bf16, bf16, bf16, MD); else L(bf16, bf16, float, MD); } \
+    else if (y_dtype == SCONF_BF16) { if (dx_dtype == SCONF_BF16) L(bf16, float, bf16, MD); else L(bf16, float, float, MD); } \
+    else if (dy_dtype == SCONF_BF16) { if (dx_dtype == SCONF_BF16) L(float, bf16, bf16, MD); else L(float, bf16, float, MD); } \
+    else { if (dx_dtype == SCONF_BF16) L(float, float, bf16, MD); else L(float, float, float, MD); }
+    if (mode == 0) { D3(0) } else { D3(1) }
+#undef D3
+#undef L
+    SCONF_LAUNCH_OK("sconf_softmax_bwd");
+    return 0;
+}
+
+// out[n] += sum over rows (bias gradients of Linear / Conv layers).
+SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, hipStream_t stream) {
+    SCONF_REQUIRE(N % 4 == 0 && ld % 4 == 0, "sconf_colsum: N and ld must be multiples of 4");
+    if (M == 0 || N == 0) return 0;
+    const int cb = cdiv(N, 256);
+    int rb = std::max(1, std::min(cdiv(M, 64), 2048 / cb));
+    const int rpb = cdiv(M, rb);
+    rb = cdiv(M, rpb);
+    dim3 g(cb, rb), b(256);
+    if (x_dtype == SCONF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), g, b, 0, stream, (const bf16*)x, out, (long)M, (int)N, (long)ld, rpb);
+    else hipLaunchKernelGGL((colsum_kernel<float>), g, b, 0, stream, (const float*)x, out, (long)M, (int)N, (long)ld, rpb);
+    SCONF_LAUNCH_OK("sconf_colsum");
+    return 0;
+}
+
+SCONF_API int sconf_mask_rows(void* x, int dtype, const int32_t* lengths, int64_t B, int64_t N, int64_t d, hipStream_t stream) {
+    SCONF_REQUIRE(d % 4 == 0, "sconf_mask_rows: d must be a multiple of 4");
+    const long total = B * N * (d / 4);
+    if (total == 0) return 0;
+    const int blocks = (int)std::min<long>(cdiv(total, 256), 8192);
+    if (dtype == SCONF_BF16) hipLaunchKernelGGL((mask_rows_kernel<bf16>), dim3(blocks), dim3(256), 0, stream, (bf16*)x, lengths, (int)B, (int)N, (int)d);
+    else hipLaunchKernelGGL((mask_rows_kernel<float>), dim3(blocks), dim3(256), 0, stream, (float*)x, lengths, (int)B, (int)N, (int)d);
+    SCONF_LAUNCH_OK("sconf_mask_rows");
+    return 0;
+}

@@ -1,0 +1,258 @@
+// bf16 MFMA GEMM for gfx950 with fused epilogues.
+//
+//   C[M,N] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// Each operand is either K-contiguous (row-major [rows][K], the nn.Linear forward layout) or
+// K-strided (stored [K][rows]); the three combinations used by the SConformerXL path are
+//   NT  (A contig, B contig)   y  = x W^T          (fused_dense.py:465-469, attention.py:513,549, decoder.py:24)
+//   NN  (A contig, B strided)  dx = dy W           (dgrad; reference fused_dense_cuda.bias_act_linear_dgrad_bgrad)
+//   TN  (A strided, B strided) dW = dy^T x         (wgrad; reference fused_dense_cuda.linear_bias_wgrad)
+// so no activation or weight is ever transposed in HBM.
+//
+// Design (MI355X): 128x128x64 block tile, 4 waves (2x2), each wave 64x64 = 4x4 tiles of
+// v_mfma_f32_16x16x32_bf16.  Operands are staged global -> registers -> LDS (issue-early /
+// write-late, double-buffered LDS, one barrier per K-tile).  K-contiguous tiles sit in LDS as
+// 128-B rows with a 16-B-chunk XOR swizzle (conflict-free ds_read_b128); K-strided tiles sit as
+// [k][rows] 256-B rows with a swizzle chosen so that ds_read_b64_tr_b16 (hardware transpose read)
+// is conflict-free.  The MFMA is issued with the operands swapped (acc = B·A^T) so that each lane
+// owns 4 *consecutive output columns* of one row: bias/residual/aux traffic and the C store are
+// 8-16 B per lane.  Block ids are remapped so that consecutive tiles stay on one XCD (shared L2).
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile
+
+struct GemmParams {
+    const bf16* A; const bf16* B; void* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    const float* bias;                              // [N] or null
+    const float* resid; long ldr;                   // f32 [M][ldr] or null  (out = resid + alpha*val)
+    const bf16* aux; long ldaux;                    // bf16 [M][ldaux] for DGELU / DSILU
+    bf16* pre; long ldpre;                          // optional pre-activation save (acc + bias)
+    float alpha;
+    int act;                                        // SconfAct
+    int out_f32;                                    // 1: C is float, 0: C is bf16
+    int atomic;                                     // 1: atomicAdd into float C (split-K / accumulate)
+    int k_per_split;                                // multiple of BK
+};
+
+__device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+
+// ---- global -> register staging of one 128 x 64 operand tile (4 x 16 B per thread) ----------
+template <bool KS>
+__device__ __forceinline__ void tile_gload(uint4 (&r)[4], const bf16* __restrict__ P, long ld, int rows,
+                                           int row0, int k0, int kend, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (!KS) {
+            const int row = c >> 3, kc = c & 7;
+            const int gr = row0 + row, gk = k0 + kc * 8;
+            if (gr < rows && gk < kend) v = *reinterpret_cast<const uint4*>(P + (long)gr * ld + gk);
+        } else {
+            const int kr = c >> 4, rc = c & 15;
+            const int gk = k0 + kr, gr = row0 + rc * 8;
+            if (gk < kend && gr < rows) v = *reinterpret_cast<const uint4*>(P + (long)gk * ld + gr);
+        }
+        r[i] = v;
+    }
+}
+
+template <bool KS>
+__device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int tid) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        int off;
+        if (!KS) {
+            const int row = c >> 3, kc = c & 7;
+            off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+        } else {
+            const int kr = c >> 4, rc = c & 15;
+            off = kr * 256 + ((rc ^ swz_strided(kr)) << 4);
+        }
+        *reinterpret_cast<uint4*>(s + off) = r[i];
+    }
+}
+
+// ---- LDS -> MFMA fragment: 16 rows [rbase, rbase+16) x 32 k of k-step kk --------------------
+template <bool KS>
+__device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int kk, int lane) {
+    if (!KS) {
+        const int r = rbase + (lane & 15), c = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+    } else {
+        const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
+        const int chunk = (rbase >> 3) + (p >> 1);
+        const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+        typedef __attribute__((address_space(3))) bf16x4* lds_p;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_p)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + (p & 1) * 8));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
+            (lds_p)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + (p & 1) * 8));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware bijective remap: consecutive logical tiles share an XCD's L2.
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int qx = nwg >> 3, rx = nwg & 7, xcd = bid & 7;
+    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (bid >> 3);
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+
+    const int kbeg = blockIdx.y * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    uint4 ra[4], rb[4];
+    tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
+    tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+    tile_lstore<AKS>(ra, smem, tid);
+    tile_lstore<BKS>(rb, smem + TILE_BYTES, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int cur = kt & 1;
+        const char* sA = smem + cur * 2 * TILE_BYTES;
+        const char* sB = sA + TILE_BYTES;
+        if (kt + 1 < nkt) {                                  // issue next tile's HBM loads early
+            tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, tid);
+            tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, tid);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            bf16x8 af[4], bfr[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) af[i] = frag_read<AKS>(sA, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BKS>(sB, wn * 64 + j * 16, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) {                                  // write late, into the other buffer
+            char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+            tile_lstore<AKS>(ra, dA, tid);
+            tile_lstore<BKS>(rb, dA + TILE_BYTES, tid);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns row m, columns n..n+3 of each 16x16 tile -------------------------
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (p.atomic) {
+                float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e] * p.alpha);
+                continue;
+            }
+            if (p.bias) {
+                float b[4]; load4(p.bias + n, b);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += b[e];
+            }
+            if (p.pre) store4(p.pre + (long)m * p.ldpre + n, v);
+            if (p.act == SCONF_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = geluf_(v[e]);
+            } else if (p.act == SCONF_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = siluf_(v[e]);
+            } else if (p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU) {
+                float a[4]; load4(p.aux + (long)m * p.ldaux + n, a);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (p.act == SCONF_ACT_DGELU ? dgeluf_(a[e]) : dsiluf_(a[e]));
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
+            if (p.resid) {
+                float r[4]; load4(p.resid + (long)m * p.ldr + n, r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] += r[e];
+            }
+            if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+            else           store4(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
+        }
+    }
+}
+
+}  // namespace
+
+// C ABI -----------------------------------------------------------------------------------------
+// layout: 0 = NT (A[M][K], B[N][K]); 1 = NN (A[M][K], B[K][N]); 2 = TN (A[K][M], B[K][N]).
+// Replaces: F.linear / fused_dense_cuda.linear_act_forward (fused_dense.py:277-279,329-332),
+// bias_act_linear_dgrad_bgrad (:354-356), linear_bias_wgrad (:113-115,338-340,375-378).
+SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
+                              int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int64_t ldc,
+                              const float* bias, const float* resid, int64_t ldr,
+                              const void* aux, int64_t ldaux, void* pre, int64_t ldpre,
+                              float alpha, int act, int out_f32, int split_k, hipStream_t stream) {
+    SCONF_REQUIRE(layout >= 0 && layout <= 2, "sconf_gemm_bf16: bad layout %d", layout);
+    SCONF_REQUIRE(M > 0 && N > 0 && K > 0, "sconf_gemm_bf16: empty problem %ld x %ld x %ld", (long)M, (long)N, (long)K);
+    SCONF_REQUIRE(M < (1L << 31) && N < (1L << 31) && K < (1L << 31), "sconf_gemm_bf16: dims must be < 2^31");
+    SCONF_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "sconf_gemm_bf16: N and ldc must be multiples of 4 (N=%ld ldc=%ld)", (long)N, (long)ldc);
+    const bool aks = layout == 2, bks = layout >= 1;
+    // 16-byte global loads: contiguous dim must be a multiple of 8 elements
+    SCONF_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "sconf_gemm_bf16: lda/ldb must be multiples of 8");
+    SCONF_REQUIRE(((uintptr_t)A & 15) == 0 && ((uintptr_t)B & 15) == 0 && ((uintptr_t)C & 7) == 0, "sconf_gemm_bf16: misaligned operand");
+    if (!aks) SCONF_REQUIRE(K % 8 == 0, "sconf_gemm_bf16: K must be a multiple of 8 for K-contiguous A");
+    else      SCONF_REQUIRE(M % 8 == 0, "sconf_gemm_bf16: M must be a multiple of 8 for K-strided A");
+    if (!bks) SCONF_REQUIRE(K % 8 == 0, "sconf_gemm_bf16: K must be a multiple of 8 for K-contiguous B");
+    else      SCONF_REQUIRE(N % 8 == 0, "sconf_gemm_bf16: N must be a multiple of 8 for K-strided B");
+    SCONF_REQUIRE(split_k >= 1, "sconf_gemm_bf16: split_k must be >= 1");
+    SCONF_REQUIRE(split_k == 1 || out_f32, "sconf_gemm_bf16: split-K accumulates with f32 atomics and needs out_f32");
+    if (act == SCONF_ACT_DGELU || act == SCONF_ACT_DSILU) SCONF_REQUIRE(aux != nullptr, "sconf_gemm_bf16: dact epilogue needs aux");
+
+    GemmParams p;
+    p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C;
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.bias = bias; p.resid = resid; p.ldr = ldr; p.aux = (const bf16*)aux; p.ldaux = ldaux;
+    p.pre = (bf16*)pre; p.ldpre = ldpre; p.alpha = alpha; p.act = act; p.out_f32 = out_f32;
+    p.atomic = split_k > 1 ? 1 : 0;
+    const int nkt = cdiv(K, BK);
+    p.k_per_split = cdiv(nkt, split_k) * BK;
+    const int splits = cdiv(K, p.k_per_split);
+    if (p.atomic) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
+
+    dim3 grid(cdiv(M, BM) * cdiv(N, BN), splits), block(256);
+    const size_t shmem = 4 * TILE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_set = true;
+    }
+    if (layout == 0)      hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, shmem, stream, p);
+    else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, shmem, stream, p);
+    else                  hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, shmem, stream, p);
+    SCONF_LAUNCH_OK("sconf_gemm_bf16");
+    return 0;
+}

@@ -1,0 +1,402 @@
+"""Autograd blocks of the SConformerXL hot path, composed from the HIP ops (``lcasr_amd.hip.ops``).
+
+Each block is ONE ``torch.autograd.Function`` covering a residual branch of the reference
+(`/root/reference/lcasr/models/sconformer_xl.py:346-372`) so that
+  * the residual stream stays f32 (what bf16-autocast gives the reference: LayerNorm outputs f32 and
+    ``bf16 + f32 -> f32``), every GEMM operand is bf16 and accumulates in f32;
+  * bias / GELU / GLU / residual / 0.5-scale live in GEMM epilogues or in the neighbouring HBM-bound kernel;
+  * the backward fuses the residual gradient into the norm backward (dx = dy + norm'(..)) and never
+    transposes an activation or a weight in HBM (NN / TN GEMM layouts).
+
+Parameters stay f32 masters in the reference's ``state_dict`` layout; a bf16 copy is cast once per forward
+(``wcast``) and reused by the backward.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+from torch.autograd import Function
+
+from .hip import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+_wcache: dict = {}
+
+
+def clear_weight_cache() -> None:
+    """Drop the per-forward bf16 weight copies (call at the start of every model forward)."""
+    _wcache.clear()
+
+
+def wcast(w: torch.Tensor) -> torch.Tensor:
+    """bf16 copy of an f32 master weight, viewed 2-D (out_features, in_features*k)."""
+    key = (w.data_ptr(), tuple(w.shape))
+    t = _wcache.get(key)
+    if t is None:
+        t = ops.cast(w.detach().reshape(w.shape[0], -1), BF16)
+        _wcache[key] = t
+    return t
+
+
+def _zeros_like_param(p: Optional[torch.Tensor]):
+    return None if p is None else torch.zeros(p.shape, dtype=F32, device=p.device)
+
+
+def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, shape, alpha: float = 1.0) -> torch.Tensor:
+    """dW[N',K'] = alpha * dy^T x  (TN GEMM, split-K over the token dimension when the tile count is small)."""
+    Mtok, Nout = dy16.shape
+    Kin = x16.shape[1]
+    sk = ops.pick_split_k(Nout, Kin, Mtok)
+    return ops.gemm(dy16, x16, 'tn', alpha=alpha, out_dtype=F32, split_k=sk).reshape(shape)
+
+
+def _bgrad(dy16: torch.Tensor, bias: Optional[torch.Tensor], alpha: float = 1.0):
+    if bias is None:
+        return None
+    out = torch.zeros(bias.shape, dtype=F32, device=bias.device)
+    ops.colsum_(dy16, out)
+    return out if alpha == 1.0 else out * alpha
+
+
+# =================================================================================================
+# standalone norm  (norm_out, decoder norms) — sconformer_xl.py:371, decoder.py:23
+# =================================================================================================
+class NormFn(Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, mode: str, eps: float, out_dtype):
+        x = x.contiguous()
+        y, mean, rstd = ops.norm_fwd(x, weight, bias, mode, eps, out_dtype)
+        ctx.save_for_backward(x, weight, mean, rstd)
+        ctx.mode, ctx.eps, ctx.has_bias = mode, eps, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, mean, rstd = ctx.saved_tensors
+        dw = torch.zeros_like(weight)
+        db = torch.zeros_like(weight) if ctx.has_bias else None
+        dx = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, x.dtype, dw, db)
+        return dx, dw, db, None, None, None
+
+
+def norm(x, weight, bias, mode='layer_norm', eps=1e-5, out_dtype=F32):
+    return NormFn.apply(x, weight, bias, mode, eps, out_dtype)
+
+
+# =================================================================================================
+# x + scale * FusedMLP(norm(x))  — Scale(0.5, PreNorm(FusedMLP)); fused_dense.py:425-498, wrappers.py:5-28
+# =================================================================================================
+class FFBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, nw, nb, w1, w2, b1, b2, scale: float, mode: str, eps: float, ckpt: int, residual: bool):
+        x = x.contiguous()
+        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        w1h, w2h = wcast(w1), wcast(w2)
+        a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu', save_pre=True)
+        y = ops.gemm(a, w2h, 'nt', bias=b2, resid=x if residual else None, alpha=scale, out_dtype=F32)
+        if ckpt >= 1:                       # checkpoint_lvl 1/2 (fused_dense.py:283-289): recompute in backward
+            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2)
+        else:
+            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, h, u, a)
+        ctx.cfg = (scale, mode, eps, ckpt, w1.shape, w2.shape, residual)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        scale, mode, eps, ckpt, w1s, w2s, residual = ctx.cfg
+        t = ctx.saved_tensors
+        x, nw, nb, mean, rstd, w1h, w2h, b1, b2 = t[:9]
+        if ckpt >= 1:
+            h, _, _ = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+            a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu', save_pre=True)
+        else:
+            h, u, a = t[9:]
+        dy = dy.contiguous()
+        dy16 = ops.cast(dy, BF16)
+        du = ops.gemm(dy16, w2h, 'nn', aux=u, act='dgelu', alpha=scale)            # (M,4d)
+        dw2 = _wgrad(dy16, a, w2s, alpha=scale)
+        db2 = _bgrad(dy16, b2, alpha=scale)
+        dw1 = _wgrad(du, h, w1s)
+        db1 = _bgrad(du, b1)
+        dh = ops.gemm(du, w1h, 'nn')
+        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
+        return dx, dnw, dnb, dw1, dw2, db1, db2, None, None, None, None, None
+
+
+def ff_block(x, nw, nb, w1, w2, b1, b2, scale=0.5, mode='layer_norm', eps=1e-5, ckpt=0, residual=True):
+    """residual=True: x + scale*MLP(norm(x)) (ConformerLayer fast path); False: the branch alone (module-level call)."""
+    return FFBlockFn.apply(x, nw, nb, w1, w2, b1, b2, scale, mode, eps, ckpt, residual)
+
+
+# =================================================================================================
+# x + out_proj(Attention(rotary(qkv(norm(x)))))  — PreNorm(Attention); attention.py:509-551
+# =================================================================================================
+class AttnBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B: int, N: int, H: int, D: int, window,
+                mode: str, eps: float, residual: bool):
+        x = x.contiguous()
+        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        if lengths is not None:
+            ops.mask_rows_(h, lengths, B, N)                                          # attention.py:511
+        wqh, woh = wcast(wqkv), wcast(wout)
+        qkv = ops.gemm(h, wqh, 'nt', bias=bqkv)                                       # (M, H*D*3), "(h d qkv)" columns
+        q, k, v = ops.rotary_qkv_fwd(qkv, cos, sin, B, N, H, D)
+        o, lse = ops.attn_fwd(q, k, v, lengths, window)                               # padded query rows come back zero
+        y = ops.gemm(o.view(B * N, H * D), woh, 'nt', bias=bout, resid=x if residual else None, out_dtype=F32)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wqh, woh, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse)
+        ctx.cfg = (B, N, H, D, window, mode, eps, wqkv.shape, wout.shape, residual)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, H, D, window, mode, eps, wqs, wos, residual = ctx.cfg
+        x, nw, nb, mean, rstd, wqh, woh, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
+        dy = dy.contiguous()
+        dy16 = ops.cast(dy, BF16)
+        o2 = o.view(B * N, H * D)
+        do = ops.gemm(dy16, woh, 'nn')                                                # (M, H*D)
+        dwo = _wgrad(dy16, o2, wos)
+        dbo = _bgrad(dy16, bout)
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, lengths, window)
+        dqkv = ops.rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D)
+        dwq = _wgrad(dqkv, h, wqs)
+        dbq = _bgrad(dqkv, bqkv)
+        dh = ops.gemm(dqkv, wqh, 'nn')
+        if lengths is not None:
+            ops.mask_rows_(dh, lengths, B, N)
+        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
+        return (dx, dnw, dnb, dwq, dwo, dbq, dbo) + (None,) * 11
+
+
+def attn_block(x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B, N, H, D, window=(-1, -1), mode='layer_norm', eps=1e-5,
+               residual=True):
+    return AttnBlockFn.apply(x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B, N, H, D, tuple(window), mode, eps, residual)
+
+
+# =================================================================================================
+# x + ConformerConvolution(norm(x))  — PreNorm(ConformerConvolution) with BatchRenorm1d; convolution.py:103-124
+# =================================================================================================
+BRN_EPS, BRN_MOMENTUM = 1e-3, 0.01                                                    # batchrenorm.py:13-14
+
+
+class ConvBlockFn(Function):
+    @staticmethod
+    def forward(ctx, x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, running_std, nbt, wpw2, bpw2, lengths,
+                B: int, N: int, training: bool, mode: str, eps: float, residual: bool):
+        x = x.contiguous()
+        d = x.shape[-1]
+        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        w1h, w2h = wcast(wpw1), wcast(wpw2)
+        g = ops.gemm(h, w1h, 'nt', bias=bpw1)                                         # (M, 2d)
+        wdw2 = wdw.detach().reshape(d, -1).contiguous()
+        hc, stats = ops.glu_dwconv_fwd(g, lengths, wdw2, bdw, B, N)
+        coef = ops.brn_finalize(stats, B * N, running_mean, running_std, nbt, brn_w, brn_b, training, BRN_EPS, BRN_MOMENTUM)
+        y2 = ops.affine_silu_fwd(hc, coef)
+        y = ops.gemm(y2, w2h, 'nt', bias=bpw2, resid=x if residual else None, out_dtype=F32)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2)
+        ctx.cfg = (B, N, training, mode, eps, wpw1.shape, wpw2.shape, wdw.shape, residual)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, N, training, mode, eps, w1s, w2s, wdws, residual = ctx.cfg
+        x, nw, nb, mean, rstd, w1h, w2h, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dy16 = ops.cast(dy, BF16)
+        dy2 = ops.gemm(dy16, w2h, 'nn')                                               # (M, d)
+        dw2 = _wgrad(dy16, y2, w2s)
+        db2 = _bgrad(dy16, bpw2)
+        ddw = torch.zeros(wdw2.shape, dtype=F32, device=x.device)
+        dbdw = torch.zeros(wdw2.shape[0], dtype=F32, device=x.device)
+        dbrnw = torch.zeros_like(brn_w); dbrnb = torch.zeros_like(brn_w)
+        dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw, dbdw, dbrnw, dbrnb)
+        dw1 = _wgrad(dg, h, w1s)
+        db1 = _bgrad(dg, bpw1)
+        dh = ops.gemm(dg, w1h, 'nn')
+        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
+        return (dx, dnw, dnb, dw1, db1, ddw.reshape(wdws), dbdw, dbrnw, dbrnb, None, None, None, dw2, db2) + (None,) * 7
+
+
+def conv_block(x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, running_std, nbt, wpw2, bpw2, lengths, B, N,
+               training, mode='layer_norm', eps=1e-5, residual=True):
+    return ConvBlockFn.apply(x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, running_std, nbt, wpw2, bpw2,
+                             lengths, B, N, training, mode, eps, residual)
+
+
+# =================================================================================================
+# self-conditioning: x + reprojection(softmax(ff(norm(x))))  — sconformer_xl.py:241-243, decoder.py:6-32
+# =================================================================================================
+class SelfCondFn(Function):
+    @staticmethod
+    def forward(ctx, x, nw, nb, wff, bff, wre, bre, has_norm: bool, mode: str, eps: float):
+        x = x.contiguous()
+        if has_norm:
+            hn, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        else:
+            hn, mean, rstd = ops.cast(x, BF16), None, None
+        wfh, wrh = wcast(wff), wcast(wre)
+        logits = ops.gemm(hn, wfh, 'nt', bias=bff)                                    # (M, V+1) bf16
+        p = ops.softmax_fwd(logits, False, BF16)
+        y = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wfh, wrh, bff, bre, hn, p)
+        ctx.cfg = (has_norm, mode, eps, wff.shape, wre.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        has_norm, mode, eps, wfs, wrs = ctx.cfg
+        x, nw, nb, mean, rstd, wfh, wrh, bff, bre, hn, p = ctx.saved_tensors
+        dy = dy.contiguous()
+        dy16 = ops.cast(dy, BF16)
+        dp = ops.gemm(dy16, wrh, 'nn')                                                # (M, V+1)
+        dwr = _wgrad(dy16, p, wrs)
+        dbr = _bgrad(dy16, bre)
+        dl = ops.softmax_bwd(p, dp, False, BF16)
+        dwf = _wgrad(dl, hn, wfs)
+        dbf = _bgrad(dl, bff)
+        dhn = ops.gemm(dl, wfh, 'nn')
+        if has_norm:
+            dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
+            dx = ops.norm_bwd(dhn, x, nw, mean, rstd, mode, eps, dy, F32, dnw, dnb)
+        else:
+            dnw = dnb = None
+            dx = dy + ops.cast(dhn, F32)
+        return dx, dnw, dnb, dwf, dbf, dwr, dbr, None, None, None
+
+
+def selfcond_block(x, nw, nb, wff, bff, wre, bre, has_norm=True, mode='layer_norm', eps=1e-5):
+    return SelfCondFn.apply(x, nw, nb, wff, bff, wre, bre, has_norm, mode, eps)
+
+
+# =================================================================================================
+# decoder head: [norm] -> norm -> Linear -> log_softmax   — sconformer_xl.py:246-247, decoder.py:22-26
+# =================================================================================================
+class HeadFn(Function):
+    @staticmethod
+    def forward(ctx, x, nw, nb, wff, bff, n_norms: int, mode: str, eps: float, return_logits: bool):
+        x = x.contiguous()
+        saved_norm = []
+        cur = x
+        for i in range(n_norms):                                                       # legacy double norm: applied twice
+            out_dt = BF16 if i == n_norms - 1 else F32
+            y, mean, rstd = ops.norm_fwd(cur, nw, nb, mode, eps, out_dt)
+            saved_norm += [cur, mean, rstd]
+            cur = y
+        hn = cur if n_norms > 0 else ops.cast(x, BF16)
+        wfh = wcast(wff)
+        logits = ops.gemm(hn, wfh, 'nt', bias=bff, out_dtype=F32)
+        out = logits if return_logits else ops.softmax_fwd(logits, True, F32)
+        ctx.save_for_backward(nw, nb, wfh, bff, hn, out, *saved_norm)
+        ctx.cfg = (n_norms, mode, eps, return_logits, wff.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        n_norms, mode, eps, return_logits, wfs = ctx.cfg
+        nw, nb, wfh, bff, hn, out = ctx.saved_tensors[:6]
+        sn = ctx.saved_tensors[6:]
+        dout = dout.contiguous()
+        dl = ops.cast(dout, BF16) if return_logits else ops.softmax_bwd(out, dout, True, BF16)
+        dwf = _wgrad(dl, hn, wfs)
+        dbf = _bgrad(dl, bff)
+        g = ops.gemm(dl, wfh, 'nn')                                                    # (M,d) bf16
+        dnw = torch.zeros_like(nw) if n_norms > 0 else None
+        dnb = _zeros_like_param(nb) if n_norms > 0 else None
+        for i in reversed(range(n_norms)):
+            xin, mean, rstd = sn[3 * i:3 * i + 3]
+            g = ops.norm_bwd(g, xin, nw, mean, rstd, mode, eps, None, F32, dnw, dnb)
+        if n_norms == 0:
+            g = ops.cast(g, F32)
+        return g, dnw, dnb, dwf, dbf, None, None, None, None
+
+
+def decoder_head(x, nw, nb, wff, bff, n_norms=1, mode='layer_norm', eps=1e-5, return_logits=False):
+    return HeadFn.apply(x, nw, nb, wff, bff, n_norms, mode, eps, return_logits)
+
+
+# =================================================================================================
+# ConvSubsampling 'dw_striding' x8  — subsampling.py:276-321, 384-428
+# =================================================================================================
+class SubsampleFn(Function):
+    @staticmethod
+    def forward(ctx, audio, w0, b0, wd1, bd1, wp1, bp1, wd2, bd2, wp2, bp2, wout, bout):
+        audio = audio.contiguous()
+        B = audio.shape[0]
+        C = w0.shape[0]
+        w0f, wd1f, wd2f = (t.detach().reshape(C, 9).contiguous() for t in (w0, wd1, wd2))
+        wp1h, wp2h, woh = wcast(wp1), wcast(wp2), wcast(wout)
+        pre0 = ops.sub_conv0_fwd(audio, w0f, b0)                                       # (B,T2,F2,C)
+        d1 = ops.sub_dwconv_fwd(pre0, wd1f, bd1)                                       # (B,T4,F4,C)
+        pre1 = ops.gemm(d1.view(-1, C), wp1h, 'nt', bias=bp1).view(d1.shape)
+        d2 = ops.sub_dwconv_fwd(pre1, wd2f, bd2)                                       # (B,N,F8,C)
+        pre2 = ops.gemm(d2.view(-1, C), wp2h, 'nt', bias=bp2).view(d2.shape)
+        N, F8 = d2.shape[1], d2.shape[2]
+        s = ops.sub_silu_transpose(pre2.view(B * N, F8, C))                            # (B*N, C*F8)
+        x = ops.gemm(s, woh, 'nt', bias=bout, out_dtype=F32)
+        ctx.save_for_backward(audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, pre0, d1, pre1, d2, pre2, s)
+        ctx.cfg = (w0.shape, wd1.shape, wp1.shape, wd2.shape, wp2.shape, wout.shape)
+        return x.view(B, N, -1)
+
+    @staticmethod
+    def backward(ctx, dx):
+        s0, sd1, sp1, sd2, sp2, so = ctx.cfg
+        audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, pre0, d1, pre1, d2, pre2, s = ctx.saved_tensors
+        B, N, F8, C = d2.shape
+        dev = dx.device
+        dx16 = ops.cast(dx.contiguous().view(B * N, -1), BF16)
+        ds = ops.gemm(dx16, woh, 'nn')                                                 # (B*N, C*F8)
+        dwo = _wgrad(dx16, s, so)
+        dbo = _bgrad(dx16, bout)
+        dpre2 = ops.sub_silu_transpose(pre2.view(B * N, F8, C), ds).view(-1, C)
+        dwp2 = _wgrad(dpre2, d2.view(-1, C), sp2)
+        dbp2 = _bgrad(dpre2, bp2)
+        dd2 = ops.gemm(dpre2, wp2h, 'nn').view(d2.shape)
+        dwd2 = torch.zeros(C, 9, dtype=F32, device=dev); dbd2 = torch.zeros(C, dtype=F32, device=dev)
+        dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2, dbd2).view(-1, C)
+        dwp1 = _wgrad(dpre1, d1.view(-1, C), sp1)
+        dbp1 = _bgrad(dpre1, bp1)
+        dd1 = ops.gemm(dpre1, wp1h, 'nn').view(d1.shape)
+        dwd1 = torch.zeros(C, 9, dtype=F32, device=dev); dbd1 = torch.zeros(C, dtype=F32, device=dev)
+        dpre0 = ops.sub_dwconv_bwd(dd1, wd1f, pre0, dwd1, dbd1)
+        dw0 = torch.zeros(C, 9, dtype=F32, device=dev); db0 = torch.zeros(C, dtype=F32, device=dev)
+        ops.sub_conv0_bwd_(dpre0, audio, dw0, db0)
+        return (None, dw0.reshape(s0), db0, dwd1.reshape(sd1), dbd1, dwp1, dbp1, dwd2.reshape(sd2), dbd2, dwp2, dbp2, dwo, dbo)
+
+
+def subsample(audio, w0, b0, wd1, bd1, wp1, bp1, wd2, bd2, wp2, bp2, wout, bout):
+    return SubsampleFn.apply(audio, w0, b0, wd1, bd1, wp1, bp1, wd2, bd2, wp2, bp2, wout, bout)
+
+
+# =================================================================================================
+# CTC  — torch.nn.CTCLoss(blank, reduction) seam, exp/train.py:104,249
+# =================================================================================================
+class CTCFn(Function):
+    @staticmethod
+    def forward(ctx, log_probs_bnc, targets, input_lengths, target_lengths, blank: int):
+        lp = log_probs_bnc.contiguous()
+        nll, ws = ops.ctc_fwd(lp, targets, input_lengths, target_lengths, blank)
+        ctx.save_for_backward(lp, nll, targets, input_lengths, target_lengths, *[w for w in ws if w is not None])
+        ctx.blank = blank
+        return nll
+
+    @staticmethod
+    def backward(ctx, dnll):
+        lp, nll, targets, input_lengths, target_lengths = ctx.saved_tensors[:5]
+        ws = tuple(ctx.saved_tensors[5:]) if len(ctx.saved_tensors) > 5 else (None, None, None)
+        g = ops.ctc_bwd(lp, ws, nll, targets, input_lengths, target_lengths, dnll.contiguous().to(F32), ctx.blank)
+        return g, None, None, None, None
+
+
+def ctc_nll(log_probs_bnc, targets, input_lengths, target_lengths, blank: int) -> torch.Tensor:
+    """Per-sample negative log-likelihoods (B,) from batch-major (B,N,C) f32 log-probs."""
+    dev = log_probs_bnc.device
+    tg = targets.to(device=dev, dtype=torch.int32).contiguous()
+    il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
+    return CTCFn.apply(log_probs_bnc, tg, il, tl, blank)

@@ -1,0 +1,377 @@
+"""Tensor-level wrappers over the sconf C ABI (include/sconf.h).
+
+Every function takes/returns torch tensors resident on the GPU, allocates its outputs, and enqueues the
+HIP kernels on torch's CURRENT stream.  torch is used only for device memory and streams.  There is no
+fallback path: a missing library or a failing call raises RuntimeError.
+
+`tests/kernel_refs.py` holds a plain-PyTorch fp32 reference with the same signature for every function
+here; the GPU parity tests compare the two.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT = {'none': 0, 'gelu': 1, 'silu': 2, 'dgelu': 3, 'dsilu': 4}
+LAYOUT = {'nt': 0, 'nn': 1, 'tn': 2}
+NORM_MODE = {'layer_norm': 0, 'rms_norm': 1, 'rms_norm_apex': 2}
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f'unsupported dtype {t.dtype}')
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu(t: torch.Tensor, what: str = 'input') -> None:
+    """The product path is HIP-only: refuse CPU tensors loudly (there is no CPU fallback)."""
+    if not t.is_cuda:
+        raise RuntimeError(f'{what} must live on the GPU: lcasr_amd runs on the MI355X HIP path only (no CPU fallback)')
+    _lib.load()
+
+
+def _chk(t: torch.Tensor, name: str, dtype=None):
+    if not t.is_cuda:
+        raise RuntimeError(f'{name} must be a GPU tensor (the HIP path has no CPU fallback)')
+    if not t.is_contiguous():
+        raise RuntimeError(f'{name} must be contiguous')
+    if dtype is not None and t.dtype != dtype:
+        raise TypeError(f'{name} must be {dtype}, got {t.dtype}')
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[torch.Tensor] = None,
+         resid: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, act: str = 'none',
+         alpha: float = 1.0, out_dtype: torch.dtype = torch.bfloat16, save_pre: bool = False, split_k: int = 1):
+    """C[M,N] = resid + alpha * act(A·B + bias)   (bf16 operands, f32 accumulate).
+
+    layout 'nt': a (M,K), b (N,K) — y = x W^T;  'nn': a (M,K), b (K,N) — dx = dy W;  'tn': a (K,M), b (K,N) — dW = dy^T x.
+    act 'dgelu'/'dsilu' multiplies by the activation derivative evaluated at aux (M,N) bf16.
+    save_pre returns (C, pre) with pre = A·B + bias in bf16.  split_k > 1 needs out_dtype float32.
+    """
+    _chk(a, 'a', torch.bfloat16); _chk(b, 'b', torch.bfloat16)
+    if layout == 'nt':
+        M, K = a.shape; N, K2 = b.shape
+    elif layout == 'nn':
+        M, K = a.shape; K2, N = b.shape
+    else:
+        K, M = a.shape; K2, N = b.shape
+    if K != K2:
+        raise ValueError(f'gemm {layout}: inner dims differ: {tuple(a.shape)} x {tuple(b.shape)}')
+    out_f32 = out_dtype == torch.float32
+    if split_k > 1:
+        c = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+    else:
+        c = torch.empty(M, N, dtype=out_dtype, device=a.device)
+    pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if save_pre else None
+    if bias is not None: _chk(bias, 'bias', torch.float32)
+    if resid is not None:
+        _chk(resid, 'resid', torch.float32)
+        if tuple(resid.shape) != (M, N): raise ValueError('resid shape mismatch')
+    if aux is not None:
+        _chk(aux, 'aux', torch.bfloat16)
+        if tuple(aux.shape) != (M, N): raise ValueError('aux shape mismatch')
+    _lib.call('sconf_gemm_bf16', LAYOUT[layout], _p(a), _p(b), _p(c), M, N, K, a.stride(0), b.stride(0), N,
+              _p(bias), _p(resid), N, _p(aux), N, _p(pre), N, float(alpha), ACT[act], int(out_f32), int(split_k), _stream())
+    return (c, pre) if save_pre else c
+
+
+def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
+    """Split-K factor for weight-gradient GEMMs (few output tiles, very long K)."""
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    if tiles >= 2 * n_cus or K <= 2048:
+        return 1
+    return int(max(1, min(K // 1024, (2 * n_cus + tiles - 1) // tiles, 16)))
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+def norm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], mode: str, eps: float,
+             out_dtype: torch.dtype) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Row norm over the last dim.  Returns (y, mean, rstd) with f32 per-row statistics."""
+    _chk(x, 'x'); _chk(weight, 'weight', torch.float32)
+    d = x.shape[-1]; M = x.numel() // d
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    mean = torch.empty(M, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+    _lib.call('sconf_norm_fwd', NORM_MODE[mode], _p(x), _dt(x), _p(weight), _p(bias), _p(y), _dt(y), _p(mean), _p(rstd),
+              M, d, float(eps), _stream())
+    return y, mean, rstd
+
+
+def norm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, mode: str,
+             eps: float, dres: Optional[torch.Tensor], dx_dtype: torch.dtype, dweight: torch.Tensor,
+             dbias: Optional[torch.Tensor]) -> torch.Tensor:
+    """dx = dres + norm'(x)·dy;  dweight / dbias are accumulated in place (f32)."""
+    _chk(dy, 'dy'); _chk(x, 'x'); _chk(dweight, 'dweight', torch.float32)
+    d = x.shape[-1]; M = x.numel() // d
+    if dres is not None: _chk(dres, 'dres', torch.float32)
+    dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    _lib.call('sconf_norm_bwd', NORM_MODE[mode], _p(dy), _dt(dy), _p(x), _dt(x), _p(weight), _p(mean), _p(rstd), _p(dres),
+              _p(dx), _dt(dx), _p(dweight), _p(dbias), M, d, float(eps), _stream())
+    return dx
+
+
+# ------------------------------------------------------------------------------------------------
+# elementwise / rows
+# ------------------------------------------------------------------------------------------------
+def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    _chk(x, 'x')
+    if x.dtype == dtype:
+        return x
+    y = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _lib.call('sconf_cast', _p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream())
+    return y
+
+
+def rotary_qkv_fwd(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], B: int, N: int, H: int, D: int):
+    """qkv (B*N, H*D*3) bf16 in the reference's "(h d qkv)" column order -> q,k,v (B,N,H,D) bf16, rotary on q,k.
+    cos/sin: (N, D/2) f32 or None (no rotary)."""
+    _chk(qkv, 'qkv', torch.bfloat16)
+    q = torch.empty(B, N, H, D, dtype=torch.bfloat16, device=qkv.device)
+    k = torch.empty_like(q); v = torch.empty_like(q)
+    use = cos is not None
+    if use: _chk(cos, 'cos', torch.float32); _chk(sin, 'sin', torch.float32)
+    _lib.call('sconf_rotary_qkv', 0, _p(qkv), _p(cos), _p(sin), _p(q), _p(k), _p(v), B, N, H, D, int(use), _stream())
+    return q, k, v
+
+
+def rotary_qkv_bwd(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos, sin, B: int, N: int, H: int, D: int) -> torch.Tensor:
+    """(dq,dk,dv) (B,N,H,D) bf16 -> dqkv (B*N, H*D*3) bf16 (transpose of rotary_qkv_fwd)."""
+    for t, n in ((dq, 'dq'), (dk, 'dk'), (dv, 'dv')): _chk(t, n, torch.bfloat16)
+    dqkv = torch.empty(B * N, H * D * 3, dtype=torch.bfloat16, device=dq.device)
+    use = cos is not None
+    _lib.call('sconf_rotary_qkv', 1, _p(dqkv), _p(cos), _p(sin), _p(dq), _p(dk), _p(dv), B, N, H, D, int(use), _stream())
+    return dqkv
+
+
+def softmax_fwd(x: torch.Tensor, log: bool, out_dtype: torch.dtype) -> torch.Tensor:
+    _chk(x, 'x')
+    Cn = x.shape[-1]; M = x.numel() // Cn
+    y = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.call('sconf_softmax_fwd', int(log), _p(x), _dt(x), _p(y), _dt(y), M, Cn, _stream())
+    return y
+
+
+def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, log: bool, out_dtype: torch.dtype) -> torch.Tensor:
+    _chk(y, 'y'); _chk(dy, 'dy')
+    Cn = y.shape[-1]; M = y.numel() // Cn
+    dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)
+    _lib.call('sconf_softmax_bwd', int(log), _p(y), _dt(y), _p(dy), _dt(dy), _p(dx), _dt(dx), M, Cn, _stream())
+    return dx
+
+
+def colsum_(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[n] += sum_m x[m, n]  (in place, f32)."""
+    _chk(x, 'x'); _chk(out, 'out', torch.float32)
+    N = x.shape[-1]; M = x.numel() // N
+    _lib.call('sconf_colsum', _p(x), _dt(x), _p(out), M, N, N, _stream())
+    return out
+
+
+def mask_rows_(x: torch.Tensor, lengths: torch.Tensor, B: int, N: int) -> torch.Tensor:
+    """Zero rows n >= lengths[b] of x viewed as (B,N,d), in place."""
+    _chk(x, 'x'); _chk(lengths, 'lengths', torch.int32)
+    d = x.numel() // (B * N)
+    _lib.call('sconf_mask_rows', _p(x), _dt(x), _p(lengths), B, N, d, _stream())
+    return x
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _strides3(t: torch.Tensor):
+    if t.stride(3) != 1:
+        raise RuntimeError('attention operands need a contiguous head_dim')
+    return (C.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lengths: Optional[torch.Tensor], window=(-1, -1),
+             scale: Optional[float] = None):
+    """q,k,v (B,N,H,D) bf16 (may be strided views) -> o (B,N,H,D) bf16, lse (B,H,N) f32."""
+    B, N, H, D = q.shape
+    o = torch.empty(B, N, H, D, dtype=torch.bfloat16, device=q.device)
+    lse = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    if lengths is not None: _chk(lengths, 'lengths', torch.int32)
+    sc = float(scale) if scale is not None else D ** -0.5
+    _lib.call('sconf_attn_fwd', _p(q), _p(k), _p(v), _p(o), _p(lse), _p(lengths), B, N, H, D, _strides3(q), _strides3(k),
+              _strides3(v), _strides3(o), int(window[0]), int(window[1]), sc, _stream())
+    return o, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale: Optional[float] = None):
+    B, N, H, D = q.shape
+    dq = torch.empty(B, N, H, D, dtype=torch.bfloat16, device=q.device)
+    dk = torch.empty_like(dq); dv = torch.empty_like(dq)
+    delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    sc = float(scale) if scale is not None else D ** -0.5
+    _lib.call('sconf_attn_bwd', _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(lengths),
+              B, N, H, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(dout), _strides3(dq), _strides3(dk),
+              _strides3(dv), int(window[0]), int(window[1]), sc, _stream())
+    return dq, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------
+# conformer conv module
+# ------------------------------------------------------------------------------------------------
+def glu_dwconv_fwd(g: torch.Tensor, lengths: Optional[torch.Tensor], w: torch.Tensor, bias: torch.Tensor, B: int, N: int):
+    """g (B*N, 2d) bf16 -> h (B*N, d) bf16 = dwconv_k(mask(GLU(g))) + bias; stats f64 (2,d) = [sum h, sum h^2]."""
+    _chk(g, 'g', torch.bfloat16); _chk(w, 'w', torch.float32); _chk(bias, 'bias', torch.float32)
+    d = g.shape[-1] // 2
+    ks = w.numel() // d
+    h = torch.empty(B * N, d, dtype=torch.bfloat16, device=g.device)
+    stats = torch.zeros(2, d, dtype=torch.float64, device=g.device)
+    _lib.call('sconf_glu_dwconv_fwd', _p(g), _p(lengths), _p(w), _p(bias), _p(h), _p(stats), B, N, d, ks, _stream())
+    return h, stats
+
+
+def brn_finalize(stats: torch.Tensor, count: int, running_mean, running_std, num_batches_tracked, weight, bias,
+                 training: bool, eps: float = 1e-3, momentum: float = 0.01) -> torch.Tensor:
+    """-> coef f32 (6,d): mean, s, r, d, A, Bc.  Training: updates the running buffers in place."""
+    d = weight.numel()
+    coef = torch.empty(6, d, dtype=torch.float32, device=weight.device)
+    _chk(num_batches_tracked, 'num_batches_tracked', torch.int64)
+    _lib.call('sconf_brn_finalize', _p(stats), int(count), _p(running_mean), _p(running_std), _p(num_batches_tracked), _p(weight),
+              _p(bias), _p(coef), d, int(training), float(eps), float(momentum), _stream())
+    return coef
+
+
+def affine_silu_fwd(h: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    _chk(h, 'h', torch.bfloat16)
+    d = h.shape[-1]
+    y = torch.empty_like(h)
+    _lib.call('sconf_affine_silu_fwd', _p(h), _p(coef), _p(y), h.numel() // d, d, _stream())
+    return y
+
+
+def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B: int, N: int, training: bool, eps: float,
+                dw, dbias, dbrn_weight, dbrn_bias) -> torch.Tensor:
+    """Backward of [GLU -> mask -> dwconv -> BatchRenorm -> SiLU]; returns dg (B*N, 2d) bf16; accumulates the 4 grads."""
+    _chk(dy, 'dy', torch.bfloat16); _chk(h, 'h', torch.bfloat16); _chk(g, 'g', torch.bfloat16)
+    d = h.shape[-1]; ks = w.numel() // d
+    dg = torch.empty(B * N, 2 * d, dtype=torch.bfloat16, device=dy.device)
+    red = torch.zeros(2, d, dtype=torch.float64, device=dy.device)
+    bcoef = torch.empty(3, d, dtype=torch.float32, device=dy.device)
+    _lib.call('sconf_convmod_bwd', _p(dy), _p(h), _p(g), _p(lengths), _p(w), _p(brn_weight), _p(coef), _p(red), _p(bcoef), _p(dg),
+              _p(dw), _p(dbias), _p(dbrn_weight), _p(dbrn_bias), B, N, d, ks, int(training), float(eps), _stream())
+    return dg
+
+
+# ------------------------------------------------------------------------------------------------
+# subsampler
+# ------------------------------------------------------------------------------------------------
+def _half(n: int) -> int:
+    return (n - 1) // 2 + 1
+
+
+def sub_conv0_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x (B,F,T) f32/bf16 -> pre0 (B,T2,F2,C) bf16 (pre-activation)."""
+    _chk(x, 'x'); _chk(w, 'w', torch.float32)
+    B, F, T = x.shape; Cc = w.shape[0]
+    y = torch.empty(B, _half(T), _half(F), Cc, dtype=torch.bfloat16, device=x.device)
+    _lib.call('sconf_sub_conv0_fwd', _p(x), _dt(x), _p(w), _p(bias), _p(y), B, F, T, Cc, _stream())
+    return y
+
+
+def sub_dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torch.Tensor:
+    """x (B,Ti,Fi,C) bf16 pre-activation -> dwconv3x3s2(SiLU(x)) + bias, (B,To,Fo,C) bf16."""
+    _chk(x, 'x', torch.bfloat16)
+    B, Ti, Fi, Cc = x.shape
+    y = torch.empty(B, _half(Ti), _half(Fi), Cc, dtype=torch.bfloat16, device=x.device)
+    _lib.call('sconf_sub_dwconv_fwd', _p(x), _p(w), _p(bias), _p(y), B, Ti, Fi, Cc, _stream())
+    return y
+
+
+def sub_dwconv_bwd(dout: torch.Tensor, w: torch.Tensor, pre_in: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor) -> torch.Tensor:
+    _chk(dout, 'dout', torch.bfloat16); _chk(pre_in, 'pre_in', torch.bfloat16)
+    B, Ti, Fi, Cc = pre_in.shape
+    dpre = torch.empty_like(pre_in)
+    _lib.call('sconf_sub_dwconv_bwd', _p(dout), _p(w), _p(pre_in), _p(dpre), _p(dw), _p(dbias), B, Ti, Fi, Cc, _stream())
+    return dpre
+
+
+def sub_conv0_bwd_(dpre0: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor) -> None:
+    _chk(dpre0, 'dpre0', torch.bfloat16); _chk(x, 'x')
+    B, F, T = x.shape; Cc = dpre0.shape[-1]
+    _lib.call('sconf_sub_conv0_bwd', _p(dpre0), _p(x), _dt(x), _p(dw), _p(dbias), B, F, T, Cc, _stream())
+
+
+def sub_silu_transpose(pre: torch.Tensor, ds: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fwd (ds None): pre (R,F8,C) -> (R, C*F8) = SiLU(pre) in the reference's c*F8+f order.
+    bwd: ds (R, C*F8) -> (R,F8,C) = ds^T * SiLU'(pre)."""
+    _chk(pre, 'pre', torch.bfloat16)
+    R, F8, Cc = pre.shape
+    if ds is None:
+        out = torch.empty(R, Cc * F8, dtype=torch.bfloat16, device=pre.device)
+        _lib.call('sconf_sub_silu_transpose', 0, _p(pre), None, _p(out), R, F8, Cc, _stream())
+    else:
+        _chk(ds, 'ds', torch.bfloat16)
+        out = torch.empty_like(pre)
+        _lib.call('sconf_sub_silu_transpose', 1, _p(pre), _p(ds), _p(out), R, F8, Cc, _stream())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CTC
+# ------------------------------------------------------------------------------------------------
+def ctc_fwd(log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor, target_lengths: torch.Tensor, blank: int):
+    """log_probs (B,N,C) f32; targets (B,Smax) int32; lengths int32 (B,).  Returns nll (B,) f32 and the workspace."""
+    _chk(log_probs, 'log_probs', torch.float32); _chk(targets, 'targets', torch.int32)
+    _chk(input_lengths, 'input_lengths', torch.int32); _chk(target_lengths, 'target_lengths', torch.int32)
+    B, N, Cn = log_probs.shape
+    Smax = targets.shape[1]
+    L = 2 * Smax + 1
+    dev = log_probs.device
+    lpg = torch.empty(B, N, L, dtype=torch.float32, device=dev)
+    alpha = torch.empty(B, N, L, dtype=torch.float32, device=dev)
+    beta = torch.empty(B, N, L, dtype=torch.float32, device=dev)
+    nll = torch.empty(B, dtype=torch.float32, device=dev)
+    _lib.call('sconf_ctc_fwd', _p(log_probs), _p(targets), _p(input_lengths), _p(target_lengths), _p(lpg), _p(alpha), _p(beta),
+              _p(nll), B, N, Cn, Smax, int(blank), _stream())
+    return nll, (lpg, alpha, beta)
+
+
+def ctc_bwd(log_probs, ws, nll, targets, input_lengths, target_lengths, grad_out: Optional[torch.Tensor], blank: int) -> torch.Tensor:
+    lpg, alpha, beta = ws
+    B, N, Cn = log_probs.shape
+    grad = torch.empty_like(log_probs)
+    if grad_out is not None: _chk(grad_out, 'grad_out', torch.float32)
+    _lib.call('sconf_ctc_bwd', _p(log_probs), _p(lpg), _p(alpha), _p(beta), _p(nll), _p(targets), _p(input_lengths),
+              _p(target_lengths), _p(grad_out), _p(grad), B, N, Cn, targets.shape[1], int(blank), _stream())
+    return grad
+
+
+# ------------------------------------------------------------------------------------------------
+# optimiser
+# ------------------------------------------------------------------------------------------------
+def sumsq_(g: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out (f64 scalar tensor) += sum(g^2)."""
+    _chk(g, 'g', torch.float32); _chk(out, 'out', torch.float64)
+    _lib.call('sconf_sumsq', _p(g), g.numel(), _p(out), _stream())
+    return out
+
+
+def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow: Optional[torch.Tensor], sumsq: Optional[torch.Tensor], max_norm: float,
+                  grad_scale: float, lr: float, momentum: float, eps: float, weight_decay: float, k: int) -> None:
+    for t, n in ((p, 'p'), (g, 'g'), (grad_sum_sq, 'grad_sum_sq'), (s, 's'), (x0, 'x0')): _chk(t, n, torch.float32)
+    _lib.call('sconf_madgrad_step', _p(p), _p(g), _p(grad_sum_sq), _p(s), _p(x0), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
+              float(grad_scale), float(lr), float(momentum), float(eps), float(weight_decay), int(k), _stream())

@@ -1,0 +1,109 @@
+"""CPU tests of the product package's HOST logic (module tree, state_dict contract, autograd wiring, length
+arithmetic, BatchRenorm buffer semantics) with the HIP op layer swapped for tests/kernel_refs.py, checked against
+the golden fixtures generated from the imported reference.  No compute call reaches libsconf_hip.so here."""
+import numpy as np
+import pytest
+import torch
+
+from common_model import TINY_CASES, build_from_fixture, grad_errors, run_step
+from conftest import golden_cfg, golden_state_dict, load_golden
+
+
+def test_state_dict_contract_and_seeded_init():
+    """Same keys, order, shapes as the reference and bit-identical init under torch.manual_seed."""
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    fx = load_golden('tiny_ln_ragged')
+    torch.manual_seed(12345)
+    m = SCConformerXL(**golden_cfg(fx))
+    ref = golden_state_dict(fx)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(ref.keys())
+    for k in ref:
+        assert sd[k].shape == ref[k].shape and sd[k].dtype == ref[k].dtype, k
+        assert torch.equal(sd[k], ref[k]), k
+    fx2 = load_golden('tiny_rms_ragged')
+    torch.manual_seed(12345)
+    m2 = SCConformerXL(**golden_cfg(fx2))
+    assert list(m2.state_dict().keys()) == [k[2:] for k in fx2.files if k.startswith('w.')]
+
+
+def test_product_path_refuses_cpu_without_fallback():
+    fx = load_golden('tiny_ln_equal')
+    m = build_from_fixture(fx)
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        m(torch.from_numpy(fx['x']))
+
+
+@pytest.mark.parametrize('case', TINY_CASES)
+def test_wiring_against_reference_fixture(emulated_ops, case):
+    """bf16-storage emulation of the kernels, f32 math: must track the reference's fp32 CPU path to bf16 noise."""
+    fx = load_golden(case)
+    m = build_from_fixture(fx)
+    r = run_step(m, fx)
+    assert torch.equal(r['length'], torch.from_numpy(fx['out_length']))
+    ref_lp = torch.from_numpy(fx['logp'])
+    d = (r['logp'] - ref_lp).abs()
+    assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (float(d.max()), float(d.mean()))
+    assert abs(r['loss'] - float(fx['loss'])) / float(fx['loss']) < 2e-3
+    errs = grad_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')})
+    worst = max(errs.values())
+    assert worst < 0.3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    for k in fx.files:
+        if k.startswith('buf.'):
+            got = m.state_dict()[k[4:]].float()
+            assert float((got - torch.from_numpy(fx[k]).float()).abs().max()) < 2e-3, k
+
+
+def test_eval_mode_uses_running_stats(emulated_ops):
+    import sys
+    from oracle import sconformer_ref as O
+    fx = load_golden('tiny_ln_ragged')
+    m = build_from_fixture(fx).eval()
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        out = m(torch.from_numpy(fx['x']), length=torch.from_numpy(fx['lengths']))
+    for k, v in m.state_dict().items():
+        assert torch.equal(v, before[k]), f'{k} changed in eval mode'
+    ref = O.forward(golden_state_dict(fx), O.make_config(**golden_cfg(fx)), torch.from_numpy(fx['x']),
+                    torch.from_numpy(fx['lengths']), training=False)
+    d = (out['final_posteriors'] - ref['final_posteriors']).abs()
+    assert float(d.max()) < 0.3 and float(d.mean()) < 0.03
+
+
+def test_module_level_branches_and_logits(emulated_ops):
+    """layer.ff1 / attend / conv called as modules return the residual BRANCH (reference semantics);
+    return_logits skips the log_softmax (decoder.py:25)."""
+    fx = load_golden('tiny_ln_equal')
+    m = build_from_fixture(fx)
+    x = torch.randn(2, 16, 64)
+    l0 = m.layers[0]
+    full = l0.ff1.fn.fn.forward_prenorm(x, l0.ff1.fn.norm, residual=True, scale=0.5)
+    branch = l0.ff1(x)
+    assert float((full - (x + branch)).abs().max()) < 1e-5
+    a = l0.attend(x, lengths=None, rotary=None)
+    c = l0.conv(x, lengths=None)
+    assert a.shape == x.shape and c.shape == x.shape
+    out_l = m(torch.from_numpy(fx['x']), return_logits=True)['final_posteriors']
+    out_p = m(torch.from_numpy(fx['x']))['final_posteriors']
+    assert float((torch.log_softmax(out_l, -1) - out_p).abs().max()) < 0.2    # BRN buffers moved between the two calls
+
+
+def test_param_groups_quirk():
+    """base.py:42-45 sends blacklist modules to no_decay and the norms to decay (kept as in the reference)."""
+    fx = load_golden('tiny_ln_equal')
+    m = build_from_fixture(fx)
+    groups = m.get_param_groups({'weight_decay': 0.1})
+    assert len(groups) == 2 and groups[0]['weight_decay'] == 0.1 and groups[1]['weight_decay'] == 0.0
+    n_decay = sum(p.numel() for p in groups[0]['params'])
+    n_norm_w = sum(p.numel() for n, p in m.named_parameters() if (n.endswith('norm.weight') or n.endswith('norm_out.weight')))
+    assert n_decay == n_norm_w
+    assert sum(p.numel() for g in groups for p in g['params']) == sum(p.numel() for p in m.parameters())
+    assert not isinstance(m.get_param_groups({'weight_decay': 0.0}), list)
+
+
+def test_unsupported_options_fail_loudly():
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    for kw in (dict(subsampling='striding'), dict(dropout_ff=0.1), dict(learned_rotary=True, use_rotary=True),
+               dict(conv_norm='batch_norm'), dict(fourier_pos_enc=True)):
+        with pytest.raises(NotImplementedError):
+            SCConformerXL(vocab_size=31, n_layers=1, d_model=32, n_heads=1, head_dim=32, subsampling_conv_channels=8, **kw)

@@ -1,0 +1,337 @@
+"""GPU parity tests, one per C-ABI entry point: HIP kernel (through lcasr_amd.hip.ops -> libsconf_hip.so) vs the
+plain-PyTorch fp32 reference of the same op (tests/kernel_refs.py) on identical seeded inputs.
+
+Tolerances (written here, per the parity contract): the kernels read bf16-rounded operands and accumulate in
+f32, so against an f32 reference fed the SAME rounded inputs
+  * f32 outputs must agree to 2e-3 of the tensor's max magnitude (accumulation order, fast exp/tanh),
+  * bf16 outputs to 1.2e-2 of the max magnitude (1 bf16 ulp = 2^-8 relative, plus the above).
+Integer / index outputs must match exactly.
+"""
+import numpy as np
+import pytest
+import torch
+
+import kernel_refs as R
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+BF, F32 = torch.bfloat16, torch.float32
+TOL_F32, TOL_BF16 = 2e-3, 1.2e-2
+
+
+@pytest.fixture(scope='module')
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip('no GPU')
+    import lcasr_amd.hip.ops as o
+    o._lib.load()
+    return o
+
+
+def dev(t):
+    return t.cuda() if isinstance(t, torch.Tensor) else t
+
+
+def close(out, ref, tol=None, name=''):
+    assert out.shape == ref.shape, f'{name}: shape {tuple(out.shape)} vs {tuple(ref.shape)}'
+    if tol is None:
+        tol = TOL_BF16 if out.dtype == BF else TOL_F32
+    o, r = out.detach().float().cpu(), ref.detach().float().cpu()
+    assert torch.isfinite(o).all(), f'{name}: non-finite output'
+    scale = float(r.abs().max()) + 1e-12
+    err = float((o - r).abs().max()) / scale
+    assert err <= tol, f'{name}: max err {err:.3e} of max|ref|={scale:.3e} > {tol}'
+
+
+def rnd(*shape, dtype=BF, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(dtype)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 72), (1000, 320, 2560), (64, 64, 8), (513, 256, 300 * 8)])
+def test_gemm_plain(ops, layout, M, N, K):
+    if layout == 'nt': a, b = rnd(M, K), rnd(N, K, seed=1)
+    elif layout == 'nn': a, b = rnd(M, K), rnd(K, N, seed=1)
+    else:
+        if M % 8: M = (M // 8) * 8
+        a, b = rnd(K, M), rnd(K, N, seed=1)
+    for od in (BF, F32):
+        out = ops.gemm(dev(a), dev(b), layout, out_dtype=od)
+        close(out, R.gemm(a, b, layout, out_dtype=od), name=f'gemm {layout} {od}')
+
+
+def test_gemm_identity_asymmetric(ops):
+    """A = I against an asymmetric B: catches a transposed C write (MFMA C/D layout)."""
+    n = 128
+    a = torch.eye(n).to(BF)
+    b = (torch.arange(n * n).reshape(n, n) % 251).float().to(BF)      # exactly representable, asymmetric
+    out = ops.gemm(dev(a), dev(b), 'nt', out_dtype=F32)                # I · B^T
+    assert torch.equal(out.cpu(), b.float().t())
+    out = ops.gemm(dev(a), dev(b), 'nn', out_dtype=F32)
+    assert torch.equal(out.cpu(), b.float())
+    out = ops.gemm(dev(b), dev(a), 'tn', out_dtype=F32)                # B^T · I
+    assert torch.equal(out.cpu(), b.float().t())
+
+
+@pytest.mark.parametrize('layout', ['nt', 'nn'])
+def test_gemm_epilogues(ops, layout):
+    M, N, K = 300, 192, 136
+    a = rnd(M, K, scale=0.5)
+    b = rnd(N, K, seed=1, scale=0.2) if layout == 'nt' else rnd(K, N, seed=1, scale=0.2)
+    bias = rnd(N, dtype=F32, seed=2)
+    resid = rnd(M, N, dtype=F32, seed=3)
+    aux = rnd(M, N, seed=4)
+    for kw in (dict(bias=bias), dict(bias=bias, act='gelu', save_pre=True), dict(act='silu'),
+               dict(aux=aux, act='dgelu', alpha=0.5), dict(aux=aux, act='dsilu'),
+               dict(bias=bias, resid=resid, alpha=0.5, out_dtype=F32), dict(resid=resid, out_dtype=F32)):
+        kd = {k: dev(v) for k, v in kw.items()}
+        out = ops.gemm(dev(a), dev(b), layout, **kd)
+        ref = R.gemm(a, b, layout, **kw)
+        if kw.get('save_pre'):
+            close(out[0], ref[0], name=f'gemm {layout} {list(kw)} out'); close(out[1], ref[1], name='pre')
+        else:
+            close(out, ref, name=f'gemm {layout} {list(kw)}')
+
+
+def test_gemm_split_k(ops):
+    K, M, N = 5000, 256, 136
+    a, b = rnd(K, M, scale=0.3), rnd(K, N, seed=1, scale=0.3)
+    for sk in (2, 5, 16):
+        out = ops.gemm(dev(a), dev(b), 'tn', alpha=0.5, out_dtype=F32, split_k=sk)
+        close(out, R.gemm(a, b, 'tn', alpha=0.5, out_dtype=F32), name=f'split_k {sk}')
+
+
+def test_gemm_rejects_bad_shapes(ops):
+    with pytest.raises(RuntimeError):
+        ops.gemm(dev(rnd(16, 12)), dev(rnd(16, 12, seed=1)), 'nt')      # K % 8 != 0
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize('mode', ['layer_norm', 'rms_norm', 'rms_norm_apex'])
+@pytest.mark.parametrize('d', [64, 256, 768, 2048])
+def test_norm_fwd_bwd(ops, mode, d):
+    M = 77
+    eps = 1e-8 if mode == 'rms_norm' else 1e-5
+    for xd, yd in ((F32, BF), (F32, F32), (BF, BF)):
+        x = rnd(M, d, dtype=xd, scale=2.0) + 0.5
+        w = rnd(d, dtype=F32, seed=1) * 0.1 + 1.0
+        b = rnd(d, dtype=F32, seed=2) * 0.1 if mode == 'layer_norm' else None
+        y, mean, rstd = ops.norm_fwd(dev(x), dev(w), dev(b), mode, eps, yd)
+        yr, mr, rr = R.norm_fwd(x, w, b, mode, eps, yd)
+        close(y, yr, name=f'norm_fwd {mode} {xd}->{yd}'); close(rstd, rr, name='rstd')
+        dy = rnd(M, d, dtype=yd, seed=3)
+        dres = rnd(M, d, dtype=F32, seed=4)
+        dw, db = torch.zeros(d).cuda(), (torch.zeros(d).cuda() if b is not None else None)
+        dwr, dbr = torch.zeros(d), (torch.zeros(d) if b is not None else None)
+        dx = ops.norm_bwd(dev(dy), dev(x), dev(w), mean, rstd, mode, eps, dev(dres), F32, dw, db)
+        dxr = R.norm_bwd(dy, x, w, mr, rr, mode, eps, dres, F32, dwr, dbr)
+        close(dx, dxr, name=f'norm_bwd dx {mode}', tol=5e-3)
+        close(dw, dwr, name='norm_bwd dw', tol=5e-3)
+        if db is not None: close(db, dbr, name='norm_bwd db', tol=5e-3)
+
+
+# ------------------------------------------------------------------------------------------------ elementwise
+def test_cast(ops):
+    x = rnd(1000003, dtype=F32)
+    assert torch.equal(ops.cast(dev(x), BF).cpu(), x.to(BF))
+    assert torch.equal(ops.cast(dev(x.to(BF)), F32).cpu(), x.to(BF).float())
+
+
+@pytest.mark.parametrize('H,D', [(2, 32), (6, 128)])
+def test_rotary_qkv(ops, H, D):
+    import sys
+    B, N = 2, 50
+    sys.path.insert(0, '.')
+    from oracle.sconformer_ref import rotary_tables
+    cos, sin = rotary_tables(N, D, 1.5e6)
+    cos, sin = cos[:, :D // 2].contiguous(), sin[:, :D // 2].contiguous()
+    qkv = rnd(B * N, H * D * 3)
+    for c, s in ((cos, sin), (None, None)):
+        q, k, v = ops.rotary_qkv_fwd(dev(qkv), dev(c), dev(s), B, N, H, D)
+        qr, kr, vr = R.rotary_qkv_fwd(qkv, c, s, B, N, H, D)
+        close(q, qr, name='rot q'); close(k, kr, name='rot k'); assert torch.equal(v.cpu(), vr)
+        d = ops.rotary_qkv_bwd(q, k, v, dev(c), dev(s), B, N, H, D)
+        close(d, R.rotary_qkv_bwd(qr, kr, vr, c, s, B, N, H, D), name='rot bwd')
+
+
+@pytest.mark.parametrize('C', [128, 4096])
+def test_softmax(ops, C):
+    M = 37
+    x = rnd(M, C, dtype=F32, scale=3.0)
+    for log, xd, yd in ((False, BF, BF), (True, F32, F32), (False, F32, F32)):
+        xi = x.to(xd)
+        y = ops.softmax_fwd(dev(xi), log, yd)
+        yr = R.softmax_fwd(xi, log, yd)
+        if log:
+            assert float((y.cpu() - yr).abs().max()) < 2e-3, 'log_softmax abs err'
+        else:
+            close(y, yr, name=f'softmax log={log}')
+        dy = rnd(M, C, dtype=yd, seed=5)
+        dx = ops.softmax_bwd(dev(yr), dev(dy), log, BF)
+        close(dx, R.softmax_bwd(yr, dy, log, BF), name=f'softmax_bwd log={log}')
+
+
+def test_colsum_and_mask(ops):
+    x = rnd(1234, 72)
+    out = torch.ones(72).cuda()
+    ops.colsum_(dev(x), out)
+    close(out, R.colsum_(x, torch.ones(72)), name='colsum', tol=2e-3)
+    B, N, d = 3, 17, 64
+    y = rnd(B * N, d)
+    ln = torch.tensor([17, 5, 0], dtype=torch.int32)
+    got = ops.mask_rows_(dev(y.clone()), dev(ln), B, N)
+    assert torch.equal(got.cpu(), R.mask_rows_(y.clone(), ln, B, N))
+
+
+# ------------------------------------------------------------------------------------------------ attention
+ATT_CASES = [  # B, N, H, D, lengths, window
+    (1, 128, 1, 32, None, (-1, -1)), (2, 200, 2, 32, None, (-1, -1)), (2, 333, 3, 128, None, (-1, -1)),
+    (3, 192, 2, 32, [192, 100, 7], (-1, -1)), (2, 260, 2, 128, [260, 131], (-1, -1)),
+    (2, 300, 2, 32, None, (16, 16)), (1, 257, 2, 128, None, (24, 8)), (2, 256, 2, 128, [256, 77], (64, 0)),
+]
+
+
+@pytest.mark.parametrize('case', ATT_CASES)
+def test_attention_fwd_bwd(ops, case):
+    B, N, H, D, lens, win = case
+    q, k, v = rnd(B, N, H, D), rnd(B, N, H, D, seed=1), rnd(B, N, H, D, seed=2)
+    ln = torch.tensor(lens, dtype=torch.int32) if lens else None
+    o, lse = ops.attn_fwd(dev(q), dev(k), dev(v), dev(ln), win)
+    orf, lser = R.attn_fwd(q, k, v, ln, win)
+    close(o, orf, name='attn o')
+    m = torch.isfinite(lser)
+    assert float((lse.cpu()[m] - lser[m]).abs().max()) < 2e-3, 'lse'
+    do = rnd(B, N, H, D, seed=3)
+    dq, dk, dv = ops.attn_bwd(dev(q), dev(k), dev(v), o, dev(do), lse, dev(ln), win)
+    dqr, dkr, dvr = R.attn_bwd(q, k, v, orf, do, lser, ln, win)
+    close(dq, dqr, name='dq', tol=2e-2); close(dk, dkr, name='dk', tol=2e-2); close(dv, dvr, name='dv', tol=2e-2)
+
+
+def test_attention_strided_views(ops):
+    """q,k,v as strided views of one packed (B,N,3,H,D) buffer — FlashSelfAttention's qkv-packed input."""
+    B, N, H, D = 2, 150, 2, 128
+    packed = rnd(B, N, 3, H, D)
+    pd = dev(packed)
+    o, _ = ops.attn_fwd(pd[:, :, 0], pd[:, :, 1], pd[:, :, 2], None)
+    orf, _ = R.attn_fwd(packed[:, :, 0], packed[:, :, 1], packed[:, :, 2], None)
+    close(o, orf, name='packed views')
+
+
+def test_attention_golden_reference_semantics(ops):
+    """Fixtures produced by the reference's attention_ref (attention.py:330-410): flash-attn window semantics."""
+    fx = load_golden('attention')
+    for name in ('full_d128', 'full_d32', 'win_d32', 'win_asym_d128'):
+        q, k, v = (torch.from_numpy(fx[f'{name}.{t}']).to(BF) for t in 'qkv')
+        lens = torch.from_numpy(fx[name + '.lens']).to(torch.int32)
+        win = tuple(int(x) for x in fx[name + '.window'])
+        ln = None if int(lens.min()) == q.shape[1] else lens
+        o, _ = ops.attn_fwd(dev(q), dev(k), dev(v), dev(ln), win)
+        close(o, torch.from_numpy(fx[name + '.o']), tol=2.5e-2, name=name)   # fixture used unrounded f32 q,k,v
+
+
+# ------------------------------------------------------------------------------------------------ conv module
+@pytest.mark.parametrize('B,N,d,lens', [(2, 100, 64, None), (3, 77, 256, [77, 30, 1]), (2, 300, 768, None)])
+def test_convmod_fwd_bwd(ops, B, N, d, lens):
+    ks = 9
+    g = rnd(B * N, 2 * d)
+    w = rnd(d, ks, dtype=F32, seed=1) * 0.3
+    bias = rnd(d, dtype=F32, seed=2) * 0.1
+    ln = torch.tensor(lens, dtype=torch.int32) if lens else None
+    h, stats = ops.glu_dwconv_fwd(dev(g), dev(ln), dev(w), dev(bias), B, N)
+    hr, statsr = R.glu_dwconv_fwd(g, ln, w, bias, B, N)
+    close(h, hr, name='glu_dwconv h')
+    close(stats.float(), statsr.float(), name='stats', tol=5e-3)
+    bw, bb = rnd(d, dtype=F32, seed=3) * 0.1 + 1, rnd(d, dtype=F32, seed=4) * 0.1
+    for training, nbt0 in ((True, 0), (True, 30000), (False, 5)):
+        rm, rs = rnd(d, dtype=F32, seed=5) * 0.1, rnd(d, dtype=F32, seed=6).abs() * 0.2 + 0.8
+        rmg, rsg, nbtg = dev(rm.clone()), dev(rs.clone()), torch.tensor(nbt0, dtype=torch.int64).cuda()
+        rmr, rsr, nbtr = rm.clone(), rs.clone(), torch.tensor(nbt0, dtype=torch.int64)
+        coef = ops.brn_finalize(dev(statsr), B * N, rmg, rsg, nbtg, dev(bw), dev(bb), training)
+        coefr = R.brn_finalize(statsr, B * N, rmr, rsr, nbtr, bw, bb, training)
+        close(coef, coefr, name=f'brn coef train={training}', tol=1e-4)
+        close(rmg, rmr, name='running_mean', tol=1e-5); close(rsg, rsr, name='running_std', tol=1e-5)
+        assert int(nbtg) == int(nbtr)
+        y = ops.affine_silu_fwd(dev(hr), dev(coefr))
+        close(y, R.affine_silu_fwd(hr, coefr), name='affine_silu')
+        dy = rnd(B * N, d, seed=7)
+        gs = [torch.zeros(d, ks), torch.zeros(d), torch.zeros(d), torch.zeros(d)]
+        gg = [t.clone().cuda() for t in gs]
+        dg = ops.convmod_bwd(dev(dy), dev(hr), dev(g), dev(ln), dev(w), dev(bw), dev(coefr), B, N, training, 1e-3, *gg)
+        dgr = R.convmod_bwd(dy, hr, g, ln, w, bw, coefr, B, N, training, 1e-3, *gs)
+        close(dg, dgr, name=f'convmod dg train={training}', tol=2e-2)
+        for a, b_, nm in zip(gg, gs, ('ddw', 'dbdw', 'dbrn_w', 'dbrn_b')):
+            close(a, b_, name=nm, tol=1e-2)
+
+
+# ------------------------------------------------------------------------------------------------ subsampler
+@pytest.mark.parametrize('B,T,C', [(2, 64, 32), (1, 203, 256)])
+def test_subsample_ops(ops, B, T, C):
+    F = 80
+    x = rnd(B, F, T, dtype=F32)
+    w0, b0 = rnd(C, 9, dtype=F32, seed=1) * 0.3, rnd(C, dtype=F32, seed=2) * 0.1
+    pre0 = ops.sub_conv0_fwd(dev(x), dev(w0), dev(b0))
+    pre0r = R.sub_conv0_fwd(x, w0, b0)
+    close(pre0, pre0r, name='conv0')
+    wd, bd = rnd(C, 9, dtype=F32, seed=3) * 0.3, rnd(C, dtype=F32, seed=4) * 0.1
+    d1 = ops.sub_dwconv_fwd(dev(pre0r), dev(wd), dev(bd))
+    d1r = R.sub_dwconv_fwd(pre0r, wd, bd)
+    close(d1, d1r, name='dwconv fwd')
+    dout = rnd(*d1r.shape, seed=5)
+    dw, db = torch.zeros(C, 9).cuda(), torch.zeros(C).cuda()
+    dwr, dbr = torch.zeros(C, 9), torch.zeros(C)
+    dpre = ops.sub_dwconv_bwd(dev(dout), dev(wd), dev(pre0r), dw, db)
+    dprer = R.sub_dwconv_bwd(dout, wd, pre0r, dwr, dbr)
+    close(dpre, dprer, name='dwconv bwd input'); close(dw, dwr, name='dwconv dw', tol=5e-3); close(db, dbr, name='dwconv db', tol=5e-3)
+    dw0, db0 = torch.zeros(C, 9).cuda(), torch.zeros(C).cuda()
+    dw0r, db0r = torch.zeros(C, 9), torch.zeros(C)
+    ops.sub_conv0_bwd_(dev(dprer), dev(x), dw0, db0)
+    R.sub_conv0_bwd_(dprer, x, dw0r, db0r)
+    close(dw0, dw0r, name='conv0 dw', tol=5e-3); close(db0, db0r, name='conv0 db', tol=5e-3)
+    pre2 = rnd(B * 7, 10, C, seed=6)
+    s = ops.sub_silu_transpose(dev(pre2))
+    sr = R.sub_silu_transpose(pre2)
+    close(s, sr, name='silu_transpose')
+    ds = rnd(*sr.shape, seed=7)
+    close(ops.sub_silu_transpose(dev(pre2), dev(ds)), R.sub_silu_transpose(pre2, ds), name='silu_transpose bwd')
+
+
+# ------------------------------------------------------------------------------------------------ CTC
+@pytest.mark.parametrize('B,N,C,S,ragged', [(2, 32, 128, 8, False), (3, 125, 128, 31, True), (2, 256, 4096, 64, False),
+                                             (2, 300, 4096, 140, True)])
+def test_ctc(ops, B, N, C, S, ragged):
+    g = torch.Generator().manual_seed(N)
+    lp = torch.log_softmax(torch.randn(B, N, C, generator=g), -1)
+    tg = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32)
+    tg[0, 1] = tg[0, 0]                                              # a repeated label (needs the blank in between)
+    il = torch.full((B,), N, dtype=torch.int32); tl = torch.full((B,), S, dtype=torch.int32)
+    if ragged:
+        il[1] = N - 17; tl[1] = max(1, S // 3); il[-1] = max(2 * S + 1, N // 2)
+    nll, ws = ops.ctc_fwd(dev(lp), dev(tg), dev(il), dev(tl), C - 1)
+    nllr, _ = R.ctc_fwd(lp, tg, il, tl, C - 1)
+    assert float(((nll.cpu() - nllr) / nllr).abs().max()) < 1e-4, (nll, nllr)
+    go = torch.tensor([1.0, 0.5, 2.0][:B])
+    grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1)
+    gradr = R.ctc_bwd(lp, None, nllr, tg, il, tl, go, C - 1)
+    close(grad, gradr, name='ctc grad', tol=2e-3)
+    assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def test_madgrad_matches_reference_fixture(ops):
+    fx = load_golden('madgrad')
+    shapes = [fx[f'p0.{i}'].shape for i in range(3)]
+    sizes = [int(np.prod(s)) for s in shapes]
+    flat = lambda pre: torch.cat([torch.from_numpy(fx[f'{pre}.{i}']).reshape(-1) for i in range(3)]).cuda()
+    p = flat('p0'); x0 = p.clone(); gss = torch.zeros_like(p); s = torch.zeros_like(p)
+    shadow = torch.empty_like(p, dtype=BF)
+    for step in range(4):
+        g = flat(f'g{step}')
+        sq = torch.zeros((), dtype=torch.float64).cuda()
+        ops.sumsq_(g, sq)
+        assert abs(float(sq) - float((g.double() ** 2).sum())) / float(sq) < 1e-5
+        ops.madgrad_step_(p, g, gss, s, x0, shadow, sq, 0.8, 1.0, 3e-3, 0.9, 1e-6, 0.0, step)
+        close(p, flat(f'p{step + 1}'), name=f'madgrad step {step}', tol=1e-5)
+        assert torch.equal(shadow, p.to(BF))

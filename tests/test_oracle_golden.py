@@ -1,0 +1,90 @@
+"""CPU tests pinning the ORACLE (oracle/*.py) against the golden fixtures generated from the imported reference
+(oracle/make_golden.py), and the numpy CTC restatement against the reference's own call (torch ctc_loss)."""
+import numpy as np
+import pytest
+import torch
+
+from common_model import TINY_CASES
+from conftest import golden_cfg, golden_state_dict, load_golden
+from oracle import ctc_ref, madgrad_ref
+from oracle import sconformer_ref as O
+
+
+@pytest.mark.parametrize('case', TINY_CASES)
+def test_oracle_matches_reference_fixture(case):
+    fx = load_golden(case)
+    sd = golden_state_dict(fx)
+    cfg = O.make_config(**golden_cfg(fx))
+    gkeys = [k[2:] for k in fx.files if k.startswith('g.')]
+    sdo = {k: v.clone().requires_grad_(k in gkeys) for k, v in sd.items()}
+    nb = {}
+    x, ln = torch.from_numpy(fx['x']), torch.from_numpy(fx['lengths'])
+    loss, scaled, out = O.train_step_loss(sdo, cfg, x, ln, torch.from_numpy(fx['targets']), torch.from_numpy(fx['target_lengths']), new_buffers=nb)
+    scaled.backward()
+    assert torch.equal(out['length'], torch.from_numpy(fx['out_length']))
+    assert float((out['final_posteriors'] - torch.from_numpy(fx['logp'])).abs().max()) < 5e-5
+    assert abs(float(loss) - float(fx['loss'])) / float(fx['loss']) < 1e-5
+    gmax = max(float(np.abs(fx['g.' + k]).max()) for k in gkeys)
+    for k in gkeys:
+        r = torch.from_numpy(fx['g.' + k])
+        assert float((sdo[k].grad - r).abs().max()) <= 1e-3 * max(float(r.abs().max()), 0.02 * gmax), k
+    for k, v in nb.items():
+        assert float((v.float() - torch.from_numpy(fx['buf.' + k]).float()).abs().max()) < 1e-6, k
+
+
+def test_oracle_c1_scalars():
+    """BASELINE config 1 (6L/256D/8H, B=2, T=1024) from torch.manual_seed(12345): loss 1882.50."""
+    fx = load_golden('c1_scalars')
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    torch.manual_seed(12345)
+    sd = SCConformerXL(**golden_cfg(fx)).state_dict()                    # bit-identical init (test_host_logic)
+    cfg = O.make_config(**golden_cfg(fx))
+    with torch.no_grad():
+        loss, _, out = O.train_step_loss(sd, cfg, torch.from_numpy(fx['x']), torch.from_numpy(fx['lengths']),
+                                         torch.from_numpy(fx['targets']), torch.from_numpy(fx['target_lengths']))
+    assert abs(float(loss) - float(fx['loss'])) / float(fx['loss']) < 1e-5
+    assert float((out['final_posteriors'][:, ::17, ::97] - torch.from_numpy(fx['logp_slice'])).abs().max()) < 5e-4
+
+
+def test_numpy_ctc_matches_torch_ctc():
+    g = torch.Generator().manual_seed(0)
+    B, N, C, S = 3, 20, 11, 5
+    lp = torch.log_softmax(torch.randn(B, N, C, generator=g), -1).requires_grad_(True)
+    tg = torch.randint(0, C - 1, (B, S), generator=g); tg[0, 1] = tg[0, 0]
+    il = torch.tensor([20, 15, 11]); tl = torch.tensor([5, 3, 0])
+    nll = torch.nn.functional.ctc_loss(lp.transpose(0, 1), tg, il, tl, blank=C - 1, reduction='none')
+    nll.sum().backward()
+    tot, nlls, grad = ctc_ref.ctc_loss_and_grad(lp.detach().numpy(), tg.numpy(), il.numpy(), tl.numpy(), C - 1)
+    assert np.allclose(nlls, nll.detach().numpy(), rtol=1e-5)
+    assert np.allclose(grad, lp.grad.numpy(), atol=2e-5)
+
+
+def test_madgrad_restatement_matches_fixture():
+    fx = load_golden('madgrad')
+    st = [dict(p=fx[f'p0.{i}'].copy(), gss=np.zeros_like(fx[f'p0.{i}']), s=np.zeros_like(fx[f'p0.{i}']), x0=fx[f'p0.{i}'].copy())
+          for i in range(3)]
+    for step in range(4):
+        grads = [fx[f'g{step}.{i}'] for i in range(3)]
+        coef, _ = madgrad_ref.clip_coef(grads, 0.8)
+        for i in range(3):
+            s_ = st[i]
+            s_['p'], s_['gss'], s_['s'] = madgrad_ref.madgrad_step(s_['p'], grads[i] * np.float32(coef), s_['gss'], s_['s'], s_['x0'], step, 3e-3)
+            assert np.abs(s_['p'] - fx[f'p{step + 1}.{i}']).max() < 1e-6
+
+
+def test_oracle_window_semantics_match_attention_ref():
+    """The oracle's local-window mask equals the reference's attention_ref (attention.py:330-410) fixtures."""
+    fx = load_golden('attention')
+    import torch.nn.functional as F
+    for name in ('win_d32', 'win_asym_d128', 'full_d32'):
+        q, k, v = (torch.from_numpy(fx[f'{name}.{t}']) for t in 'qkv')
+        B, N, H, D = q.shape
+        win = tuple(int(x) for x in fx[name + '.window'])
+        lens = torch.from_numpy(fx[name + '.lens'])
+        s = torch.einsum('bihd,bjhd->bhij', q, k) / D ** 0.5
+        i = torch.arange(N)[:, None]; j = torch.arange(N)[None, :]
+        left = win[0] if win[0] >= 0 else N; right = win[1] if win[1] >= 0 else N
+        mask = ((j < i - left) | (j > i + right))[None, None] | (j[None, None] >= lens[:, None, None, None])
+        o = torch.einsum('bhij,bjhd->bihd', s.masked_fill(mask, float('-inf')).softmax(-1), v)
+        o = o.masked_fill((torch.arange(N)[None, :] >= lens[:, None])[:, :, None, None], 0.0)
+        assert float((o - torch.from_numpy(fx[name + '.o'])).abs().max()) < 1e-5, name
