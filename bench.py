@@ -1,0 +1,181 @@
+#!/usr/bin/env python
+"""Headline benchmark: SConformerXL training step (forward + CTC + backward + clip + MADGRAD [+ RCCL gradient
+all-reduce]) on synthetic mel, BASELINE.json config 3: 6L/768D/6H rotary theta=1.5M, seq=16384, bf16 compute.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0): metric = spectrogram-frames/sec (whole job), plus
+  roofline     : the dominant kernel (NT bf16 MFMA GEMM) timed live with HIP events on its stream over the timed region,
+                 algorithmic FLOPs = 2*M*N*K per launch, peak = 2.5 PFLOP/s dense bf16;
+  cpu_baseline : the CPU oracle (oracle/sconformer_ref.py, fp32, all host cores) on a bounded sample of the same
+                 workload (N=1, rank 0 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    'c3': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
+                          use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
+                          default_norm='layer_norm', bias_in_ff=False), T=16384, batch=16,
+               name='6L/768D/6H SConformerXL, seq=16384, rotary theta=1.5M'),
+    'c2': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
+                          use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
+                          default_norm='layer_norm', bias_in_ff=False), T=1024, batch=64,
+               name='6L/768D/6H SConformerXL, seq=1024'),
+    'c1': dict(model=dict(vocab_size=4095, n_layers=6, d_model=256, n_heads=8, head_dim=32, subsampling_conv_channels=256,
+                          use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
+                          default_norm='layer_norm', bias_in_ff=False), T=1024, batch=2,
+               name='6L/256D/8H SConformerXL, seq=1024'),
+}
+PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+
+
+class GemmTimer:
+    """HIP-event timing of every NT GEMM launch (the dominant kernel) on the stream it is launched on."""
+
+    def __init__(self):
+        self.events, self.flops, self.enabled = [], 0.0, False
+
+    def install(self):
+        import lcasr_amd.hip.ops as ops
+        inner = ops.gemm
+        timer = self
+
+        def gemm(a, b, layout='nt', **kw):
+            if not timer.enabled or layout != 'nt':
+                return inner(a, b, layout, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = inner(a, b, layout, **kw)
+            e1.record()
+            timer.events.append((e0, e1))
+            timer.flops += 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            return out
+        ops.gemm = gemm
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        ach = self.flops / (ms * 1e-3)
+        return dict(bound='mfma', kernel='gemm_kernel<NT> (sconf_gemm_bf16 layout 0)', achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
+                    unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=None, launches=len(self.events),
+                    avg_launch_us=round(ms * 1e3 / len(self.events), 2))
+
+
+def cpu_baseline(cfg_name: str):
+    """Oracle (CPU fp32 restatement of the reference path) on a bounded sample: B=1 of the same config, one
+    forward+CTC+backward after no warm-up, all host cores."""
+    from oracle import sconformer_ref as O
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    cfg = CONFIGS[cfg_name]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(12345)
+    sd = {k: v.clone() for k, v in SCConformerXL(**cfg['model']).state_dict().items()}
+    gk = {k for k, v in sd.items() if v.is_floating_point() and 'running' not in k and 'rotary' not in k}
+    sd = {k: (v.requires_grad_(True) if k in gk else v) for k, v in sd.items()}
+    T = cfg['T']
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 80, T, generator=g)
+    N = T // 8
+    tg = torch.randint(0, cfg['model']['vocab_size'], (1, max(N // 4, 1)), generator=g)
+    t0 = time.perf_counter()
+    loss, scaled, _ = O.train_step_loss(sd, O.make_config(**cfg['model']), x, torch.tensor([T]), tg, torch.tensor([tg.shape[1]]))
+    scaled.backward()
+    dt = time.perf_counter() - t0
+    return dict(value=round(T / dt, 1), unit='spectrogram-frames/sec', cores=cores, kind='port',
+                sample=f'oracle fp32 forward+CTC+backward, B=1 x T={T}, 1 step, no warm-up ({dt:.1f} s)', loss=round(float(loss), 3))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='c3', choices=list(CONFIGS))
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config value)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+    assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+
+    import lcasr_amd  # noqa: F401
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    from lcasr_amd.parallel import broadcast_module_state
+    from lcasr_amd.train import Trainer, synthetic_batch
+
+    cfg = CONFIGS[args.config]
+    B = args.batch or cfg['batch']
+    T = cfg['T']
+    torch.manual_seed(12345)                                                  # exp/train.py:363
+    model = SCConformerXL(**cfg['model']).cuda().train()
+    if world > 1:
+        broadcast_module_state(model)
+    trainer = Trainer(model, lr=3e-3, clip_value=0.8, global_batch=B * world)
+    audio, lengths, targets, tl = synthetic_batch(B, T, cfg['model']['vocab_size'], seed=rank)
+
+    timer = GemmTimer()
+    timer.install()
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = trainer.step(audio, lengths, targets, tl)
+    sync()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = trainer.step(audio, lengths, targets, tl)
+    sync()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax)
+
+    if rank == 0:
+        frames = B * T * world * args.steps
+        res = {
+            'metric': 'spectrogram-frames/sec (6L/768D, seq=16384)' if args.config == 'c3' else f'spectrogram-frames/sec ({args.config})',
+            'value': round(frames / dt, 1), 'unit': 'spectrogram-frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': cfg['name'] + ', fwd+CTC+bwd+clip+MADGRAD', 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
+                       'parallelism': f'dp{world}', 'loss_last_step': round(float(loss), 3)},
+            'per_gpu_value': round(frames / dt / world, 1),
+            'roofline': timer.summary(),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res['cpu_baseline'] = cpu_baseline(args.config)
+            res['gpu_over_cpu'] = round(res['value'] / res['cpu_baseline']['value'], 1)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

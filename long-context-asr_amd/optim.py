@@ -1,0 +1,99 @@
+"""MADGRAD on the MI355X: one fused kernel over FLAT f32 parameter / gradient / state buffers
+(replaces lcasr/optim/madgrad.py:19-212, dense momentum branch, and the clip + GradScaler logic of
+exp/train.py:46-61).
+
+`FlatParams` re-points every parameter's storage (and its .grad) at one contiguous buffer per parameter group, so
+  * the optimiser step, the global-norm clip and zero_grad are single launches,
+  * data-parallel gradient all-reduce works on contiguous slices (parallel.GradSync) without bucket copies.
+"""
+from __future__ import annotations
+
+import math
+from typing import Iterable, List, Optional
+
+import torch
+
+from .hip import ops
+
+
+class FlatParams:
+    """Flatten a list of parameters into one f32 buffer (+ a gradient buffer of the same shape)."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params]
+        assert self.params, 'no parameters'
+        dev = self.params[0].device
+        assert all(p.dtype == torch.float32 and p.device == dev for p in self.params), 'f32 parameters on one device expected'
+        self.offsets, n = [], 0
+        for p in self.params:
+            self.offsets.append(n)
+            n += (p.numel() + 3) // 4 * 4                     # keep every tensor 16-B aligned
+        self.numel = n
+        self.data = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        for p, o in zip(self.params, self.offsets):
+            self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.data[o:o + p.numel()].view(p.shape)
+            p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self):
+        self.grad.zero_()
+        for p, o in zip(self.params, self.offsets):           # re-attach if something replaced .grad
+            if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+    def gather_stray_grads(self):
+        """If autograd replaced a .grad tensor (instead of accumulating in place) copy it back into the flat buffer."""
+        for p, o in zip(self.params, self.offsets):
+            if p.grad is not None and p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
+                self.grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = self.grad[o:o + p.numel()].view(p.shape)
+
+
+class MADGRAD(torch.optim.Optimizer):
+    """Drop-in for lcasr.optim.madgrad.MADGRAD(params, lr, momentum, weight_decay, eps) with a fused HIP step.
+
+    step(max_norm=..., grad_scale=...) additionally performs torch.nn.utils.clip_grad_norm_(params, max_norm) and the
+    GradScaler inf/nan skip inside the same launch sequence (no host sync)."""
+
+    def __init__(self, params, lr: float = 1e-2, momentum: float = 0.9, weight_decay: float = 0, eps: float = 1e-6,
+                 decouple_decay: bool = False):
+        if momentum <= 0 or momentum >= 1:
+            raise ValueError(f'Momentum {momentum} must be in (0,1) (the momentum == 0 branch is not implemented)')
+        if lr < 0 or weight_decay < 0 or eps < 0:
+            raise ValueError('lr, weight_decay and eps must be non-negative')
+        if decouple_decay:
+            raise NotImplementedError('decouple_decay is EXPERIMENTAL in the reference and unused by its configs')
+        super().__init__(params, dict(lr=lr, eps=eps, momentum=momentum, weight_decay=weight_decay, decouple_decay=False))
+        self.flat: List[FlatParams] = []
+        for group in self.param_groups:
+            fp = FlatParams(group['params'])
+            self.flat.append(fp)
+            group['_gss'] = torch.zeros_like(fp.data)
+            group['_s'] = torch.zeros_like(fp.data)
+            group['_x0'] = fp.data.clone()
+        self.k = 0
+        self._sumsq = torch.zeros((), dtype=torch.float64, device=self.flat[0].data.device)
+        self.last_sumsq: Optional[torch.Tensor] = None
+
+    def zero_grad(self, set_to_none: bool = False):
+        for fp in self.flat:
+            fp.zero_grad()
+
+    @torch.no_grad()
+    def step(self, closure=None, max_norm: float = 0.0, grad_scale: float = 1.0):
+        loss = closure() if closure is not None else None
+        self._sumsq.zero_()
+        for fp in self.flat:
+            fp.gather_stray_grads()
+            ops.sumsq_(fp.grad, self._sumsq)
+        for group, fp in zip(self.param_groups, self.flat):
+            ops.madgrad_step_(fp.data, fp.grad, group['_gss'], group['_s'], group['_x0'], None, self._sumsq, max_norm,
+                              grad_scale, group['lr'], group['momentum'], group['eps'], group['weight_decay'], self.k)
+        self.k += 1
+        self.last_sumsq = self._sumsq
+        return loss
+
+    def grad_norm(self) -> float:
+        """Host value of the last step's global gradient norm (syncs)."""
+        return math.sqrt(float(self._sumsq))

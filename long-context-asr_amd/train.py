@@ -1,0 +1,53 @@
+"""Training-step counterpart of the hot loop in exp/train.py:212-293 (one chunk == one optimiser step, the paper
+schedule `backprop_every: 1`), on synthetic mel batches, with optional single-node data parallelism.
+
+    out  = model(audio, length)                                           # train.py:236
+    loss = CTCLoss(blank=V, 'sum')(out.transpose(0,1), txt, out_len, txt_len)   # train.py:104,249
+    (loss / (chunk_size * batch_size) * 100).backward()                  # train.py:275  (GLOBAL batch under DDP)
+    clip_grad_norm_(0.8); MADGRAD.step(); zero_grad()                     # train.py:46-61
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from .losses import CTCLoss
+from .optim import MADGRAD
+from .parallel import GradSync
+
+
+def synthetic_batch(B: int, T: int, vocab_size: int, seed: int = 0, device='cuda', dtype=torch.float32):
+    """mel ~ N(0,1) (B,80,T), lengths = T, targets uniform in [0,V), S = N/4 tokens per sample."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, 80, T, generator=g).to(dtype)
+    N = ((T - 1) // 2 + 1 - 1) // 2 + 1
+    N = (N - 1) // 2 + 1
+    S = max(N // 4, 1)
+    targets = torch.randint(0, vocab_size, (B, S), generator=g)
+    return (x.to(device), torch.full((B,), T, dtype=torch.long, device=device), targets.to(device),
+            torch.full((B,), S, dtype=torch.long, device=device))
+
+
+class Trainer:
+    def __init__(self, model, lr: float = 3e-3, clip_value: float = 0.8, global_batch: Optional[int] = None,
+                 bucket_bytes: int = 64 << 20):
+        self.model = model
+        self.opt = MADGRAD(model.parameters(), lr=lr)
+        self.ctc = CTCLoss(blank=model.decoder.num_classes - 1, reduction='sum')
+        self.clip_value = clip_value
+        self.global_batch = global_batch
+        fp = self.opt.flat[0]
+        self.sync = GradSync(fp.params, fp.grad, fp.offsets, bucket_bytes)
+
+    def step(self, audio, lengths, targets, target_lengths):
+        """One optimiser step; returns the (device) summed CTC loss of this rank's shard."""
+        B, _, T = audio.shape
+        out = self.model(audio, length=lengths)
+        loss = self.ctc(out['final_posteriors'].transpose(0, 1), targets, out['length'], target_lengths)
+        gb = self.global_batch or B * self.sync.world
+        (loss / (T * gb) * 100).backward()
+        self.sync.finish()
+        self.opt.step(max_norm=self.clip_value)
+        self.opt.zero_grad()
+        return loss.detach()

@@ -179,7 +179,9 @@ def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale=None):
         s = torch.einsum('bihd,bjhd->bhij', qf, kf) * sc
         ok = _attn_mask(B, N, lengths, window, q.device)
         s = s.masked_fill(~ok[:, None], float('-inf'))
-        p = torch.softmax(s, dim=-1)
+        dead = ~ok.any(-1)                                  # query rows with no visible key (padding + window)
+        s = s.masked_fill(dead[:, None, :, None], 0.0)
+        p = torch.softmax(s, dim=-1) * (~dead)[:, None, :, None]
         oo = torch.einsum('bhij,bjhd->bihd', p, vf)
         g = dout.to(f32)
         if lengths is not None:

@@ -33,13 +33,13 @@ def dev(t):
     return t.cuda() if isinstance(t, torch.Tensor) else t
 
 
-def close(out, ref, tol=None, name=''):
+def close(out, ref, tol=None, name='', floor=0.0):
     assert out.shape == ref.shape, f'{name}: shape {tuple(out.shape)} vs {tuple(ref.shape)}'
     if tol is None:
         tol = TOL_BF16 if out.dtype == BF else TOL_F32
     o, r = out.detach().float().cpu(), ref.detach().float().cpu()
     assert torch.isfinite(o).all(), f'{name}: non-finite output'
-    scale = float(r.abs().max()) + 1e-12
+    scale = max(float(r.abs().max()), floor) + 1e-12
     err = float((o - r).abs().max()) / scale
     assert err <= tol, f'{name}: max err {err:.3e} of max|ref|={scale:.3e} > {tol}'
 
@@ -262,8 +262,11 @@ def test_convmod_fwd_bwd(ops, B, N, d, lens):
         dg = ops.convmod_bwd(dev(dy), dev(hr), dev(g), dev(ln), dev(w), dev(bw), dev(coefr), B, N, training, 1e-3, *gg)
         dgr = R.convmod_bwd(dy, hr, g, ln, w, bw, coefr, B, N, training, 1e-3, *gs)
         close(dg, dgr, name=f'convmod dg train={training}', tol=2e-2)
+        # the dw-conv bias gradient is analytically ~0 in training mode (BatchRenorm removes the mean): compare it on
+        # the scale of the dw-conv weight gradient
+        wscale = float(gs[0].abs().max())
         for a, b_, nm in zip(gg, gs, ('ddw', 'dbdw', 'dbrn_w', 'dbrn_b')):
-            close(a, b_, name=nm, tol=1e-2)
+            close(a, b_, name=nm, tol=1e-2, floor=wscale if nm == 'dbdw' else 0.0)
 
 
 # ------------------------------------------------------------------------------------------------ subsampler
