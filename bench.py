@@ -73,13 +73,26 @@ class GemmTimer:
                     avg_launch_us=round(ms * 1e3 / len(self.events), 2))
 
 
+def host_cores() -> int:
+    """CPU threads this process may really use: cgroup quota if set, else the affinity mask, capped at the one-GPU
+    box share (16) so the oracle is not oversubscribed on a 256-thread host it only owns a slice of."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, int(os.environ.get('SCONF_CPU_THREADS', '16'))))
+
+
 def cpu_baseline(cfg_name: str):
     """Oracle (CPU fp32 restatement of the reference path) on a bounded sample: B=1 of the same config, one
     forward+CTC+backward after no warm-up, all host cores."""
     from oracle import sconformer_ref as O
     from lcasr_amd.models.sconformer_xl import SCConformerXL
     cfg = CONFIGS[cfg_name]
-    cores = os.cpu_count() or 1
+    cores = host_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(12345)
     sd = {k: v.clone() for k, v in SCConformerXL(**cfg['model']).state_dict().items()}

@@ -32,11 +32,15 @@ int sconf_num_cus(void);
  * layout NN: A[M][K], B[K][N]  (dgrad: fused_dense_cuda.bias_act_linear_dgrad_bgrad, fused_dense.py:354-356)
  * layout TN: A[K][M], B[K][N]  (wgrad: fused_dense_cuda.linear_bias_wgrad, fused_dense.py:113-115,338-340,375-378)
  * act DGELU/DSILU multiply by act'(aux[M][N]); pre (nullable) receives A·B+bias in bf16 (save_pre_act);
- * split_k > 1 accumulates into a PRE-ZEROED f32 C with atomics (plain epilogue only). */
+ * split_k > 1 (plain epilogue only): C must hold sconf_gemm_num_splits(K, split_k) f32 slabs of M*ldc elements; slab s
+ * receives the partial sum of K-range s with plain stores (deterministic); combine with sconf_splitk_reduce. */
 int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C, int64_t M, int64_t N, int64_t K,
                     int64_t lda, int64_t ldb, int64_t ldc, const float* bias, const float* resid, int64_t ldr,
                     const void* aux, int64_t ldaux, void* pre, int64_t ldpre, float alpha, int act, int out_f32,
                     int split_k, sconf_stream_t stream);
+
+int sconf_gemm_num_splits(int64_t K, int split_k);
+int sconf_splitk_reduce(const float* slab, float* out, int64_t splits, int64_t n, int accumulate, sconf_stream_t stream);
 
 /* Row norms over the last dim d <= 2048 (apex FusedLayerNorm/FusedRMSNorm, torch LayerNorm, local RMSNorm:
  * sconformer_xl.py:14-17, normalisation.py:6-47).  mean/rstd: f32 [M] saved statistics. */

@@ -18,6 +18,10 @@
 // owns 4 *consecutive output columns* of one row: bias/residual/aux traffic and the C store are
 // 8-16 B per lane.  Block ids are remapped so that consecutive tiles stay on one XCD (shared L2).
 #include "common.h"
+#include <stdlib.h>
+#include <algorithm>
+
+SCONF_API int sconf_num_cus(void);
 
 namespace {
 
@@ -35,8 +39,9 @@ struct GemmParams {
     float alpha;
     int act;                                        // SconfAct
     int out_f32;                                    // 1: C is float, 0: C is bf16
-    int atomic;                                     // 1: atomicAdd into float C (split-K / accumulate)
+    long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
     int k_per_split;                                // multiple of BK
+    int splits;
 };
 
 __device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -79,6 +84,32 @@ __device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int ti
     }
 }
 
+// ---- global -> LDS directly (LDS-DMA, global_load_lds_dwordx4): no staging VGPRs, no ds_write ----------------
+// The LDS destination of one wave-instruction is wave-uniform base + lane*16 (linear), so the swizzle is applied to
+// the per-lane SOURCE address and undone by the same involution on the fragment read (rule "both sides or neither").
+// Rows beyond the matrix are clamped to a valid row (their products are never stored); the K range must be whole
+// 64-deep tiles (checked on the host) because a DMA cannot zero-fill.
+template <bool KS>
+__device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, int rows, int row0, int k0, char* s, int tid) {
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = tid + 256 * i;
+        const bf16* src;
+        if (!KS) {
+            const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
+            const int gr = min(row0 + row, rows - 1);
+            src = P + (long)gr * ld + k0 + kc * 8;
+        } else {
+            const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
+            const int gr = min(row0 + rc * 8, rows - 8);
+            src = P + (long)(k0 + kr) * ld + gr;
+        }
+        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s + ((tid & ~63) + 256 * i) * 16), 16, 0, 0);
+    }
+}
+
 // ---- LDS -> MFMA fragment: 16 rows [rbase, rbase+16) x 32 k of k-step kk --------------------
 template <bool KS>
 __device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int kk, int lane) {
@@ -98,66 +129,8 @@ __device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int kk, in
     }
 }
 
-template <bool AKS, bool BKS>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // XCD-aware bijective remap: consecutive logical tiles share an XCD's L2.
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int qx = nwg >> 3, rx = nwg & 7, xcd = bid & 7;
-    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (bid >> 3);
-    const int tiles_n = (p.N + BN - 1) / BN;
-    const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
-
-    const int kbeg = blockIdx.y * p.k_per_split;
-    const int kend = min(p.K, kbeg + p.k_per_split);
-    const int nkt = (kend - kbeg + BK - 1) / BK;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    uint4 ra[4], rb[4];
-    tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
-    tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
-    tile_lstore<AKS>(ra, smem, tid);
-    tile_lstore<BKS>(rb, smem + TILE_BYTES, tid);
-    __syncthreads();
-
-    for (int kt = 0; kt < nkt; ++kt) {
-        const int cur = kt & 1;
-        const char* sA = smem + cur * 2 * TILE_BYTES;
-        const char* sB = sA + TILE_BYTES;
-        if (kt + 1 < nkt) {                                  // issue next tile's HBM loads early
-            tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, tid);
-            tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, tid);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            bf16x8 af[4], bfr[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) af[i] = frag_read<AKS>(sA, wm * 64 + i * 16, kk, lane);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BKS>(sB, wn * 64 + j * 16, kk, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-        }
-        if (kt + 1 < nkt) {                                  // write late, into the other buffer
-            char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            tile_lstore<AKS>(ra, dA, tid);
-            tile_lstore<BKS>(rb, dA + TILE_BYTES, tid);
-        }
-        __syncthreads();
-    }
-
-    // ---- epilogue: lane owns row m, columns n..n+3 of each 16x16 tile -------------------------
+// ---- epilogue: lane owns row m, columns n..n+3 of each 16x16 tile ---------------------------------------------
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
@@ -167,12 +140,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.atomic) {
-                float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) atomicAdd(c + e, v[e] * p.alpha);
-                continue;
-            }
             if (p.bias) {
                 float b[4]; load4(p.bias + n, b);
 #pragma unroll
@@ -197,9 +164,150 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] += r[e];
             }
-            if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n, v);
+            if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
             else           store4(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
         }
+    }
+}
+
+// Work item v in [0, ntiles * splits) -> (m0, n0, K range).
+//  1. XCD-aware bijective remap: workgroups v and v+8 share an XCD (round-robin dispatch), so give each XCD a CONTIGUOUS
+//     range of logical ids: the ~64 workgroups resident on one XCD then work on ~64 consecutive logical ids.
+//  2. Logical ids are ordered split-major, then in groups of GM row-panels with the row index fastest inside a group,
+//     so 64 consecutive ids cover a GM x 8 patch of output tiles of ONE K-split: every A panel and every B panel is
+//     fetched from HBM once per patch and then served by that XCD's 4 MiB L2 (the weight matrices of the model,
+//     4.7-6.3 MB, do not fit an L2, so a row-major tile order re-streams them for every 128-row panel).
+constexpr int GM = 8;
+struct WorkItem { int m0, n0, kbeg, kend, split; };
+__device__ __forceinline__ WorkItem tile_coords(const GemmParams& p, int v, int total, int ntiles, int tiles_m, int tiles_n) {
+    const int qx = total >> 3, rx = total & 7, xcd = v & 7;
+    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (v >> 3);
+    const int split = lid / ntiles, t = lid - split * ntiles;
+    const int per_group = GM * tiles_n;
+    const int g = t / per_group, r = t - g * per_group;
+    const int first_m = g * GM, gm = min(GM, tiles_m - first_m);
+    WorkItem w;
+    w.m0 = (first_m + r % gm) * BM; w.n0 = (r / gm) * BN;
+    w.split = split;
+    w.kbeg = split * p.k_per_split; w.kend = min(p.K, w.kbeg + p.k_per_split);
+    return w;
+}
+
+template <bool AKS, bool BKS>
+__device__ __forceinline__ void tile_mma(const char* sA, const char* sB, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+        bf16x8 af[4], bfr[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) af[i] = frag_read<AKS>(sA, wm * 64 + i * 16, kk, lane);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BKS>(sB, wn * 64 + j * 16, kk, lane);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    }
+}
+
+// GLDS = true : persistent workgroups (gridDim.x <= 2 per CU) walk output tiles v = blockIdx.x, +gridDim.x, ...; operands
+//               stream global -> LDS by LDS-DMA one K-tile ahead, ACROSS tile boundaries, so a tile's epilogue stores
+//               overlap the next tile's first loads and there is no per-tile prologue bubble.
+// GLDS = false: general path (any K): one tile per workgroup, register-staged (issue-early / write-late).
+template <bool AKS, bool BKS, bool GLDS>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM - 1) / BM;
+    const int ntiles = tiles_m * tiles_n, total = ntiles * p.splits;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int v = blockIdx.x;
+    if (v >= total) return;
+    WorkItem w = tile_coords(p, v, total, ntiles, tiles_m, tiles_n);
+
+    if (GLDS) {
+        tile_glds<AKS>(p.A, p.lda, p.M, w.m0, w.kbeg, smem, tid);
+        tile_glds<BKS>(p.B, p.ldb, p.N, w.n0, w.kbeg, smem + TILE_BYTES, tid);
+        __syncthreads();                                     // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
+        int cur = 0;
+        while (true) {
+            const int vn = v + gridDim.x;
+            WorkItem wn_ = w;
+            if (vn < total) wn_ = tile_coords(p, vn, total, ntiles, tiles_m, tiles_n);
+            const int nkt = (w.kend - w.kbeg) / BK;
+            for (int kt = 0; kt < nkt; ++kt) {
+                const char* sA = smem + cur * 2 * TILE_BYTES;
+                char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+                if (kt + 1 < nkt) {                          // next K-tile streams into the other buffer during the MFMAs
+                    tile_glds<AKS>(p.A, p.lda, p.M, w.m0, w.kbeg + (kt + 1) * BK, dA, tid);
+                    tile_glds<BKS>(p.B, p.ldb, p.N, w.n0, w.kbeg + (kt + 1) * BK, dA + TILE_BYTES, tid);
+                } else if (vn < total) {                     // ... or the NEXT work item's first K-tile
+                    tile_glds<AKS>(p.A, p.lda, p.M, wn_.m0, wn_.kbeg, dA, tid);
+                    tile_glds<BKS>(p.B, p.ldb, p.N, wn_.n0, wn_.kbeg, dA + TILE_BYTES, tid);
+                }
+                tile_mma<AKS, BKS>(sA, sA + TILE_BYTES, acc, wm, wn, lane);
+                if (kt == nkt - 1) {
+                    gemm_epilogue(p, acc, w.m0, w.n0, w.split, wm, wn, lane);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __syncthreads();
+                cur ^= 1;
+            }
+            if (vn >= total) break;
+            v = vn; w = wn_;
+        }
+    } else {
+        const int kbeg = w.kbeg, kend = w.kend, m0 = w.m0, n0 = w.n0;
+        const int nkt = (kend - kbeg + BK - 1) / BK;
+        uint4 ra[4], rb[4];
+        tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
+        tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
+        tile_lstore<AKS>(ra, smem, tid);
+        tile_lstore<BKS>(rb, smem + TILE_BYTES, tid);
+        __syncthreads();
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int cur = kt & 1;
+            const char* sA = smem + cur * 2 * TILE_BYTES;
+            if (kt + 1 < nkt) {                              // issue next tile's HBM loads early
+                tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg + (kt + 1) * BK, kend, tid);
+                tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg + (kt + 1) * BK, kend, tid);
+            }
+            tile_mma<AKS, BKS>(sA, sA + TILE_BYTES, acc, wm, wn, lane);
+            if (kt + 1 < nkt) {                              // write late, into the other buffer
+                char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
+                tile_lstore<AKS>(ra, dA, tid);
+                tile_lstore<BKS>(rb, dA + TILE_BYTES, tid);
+            }
+            __syncthreads();
+        }
+        gemm_epilogue(p, acc, m0, n0, w.split, wm, wn, lane);
+    }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, long n, int accumulate) {
+    long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * blockDim.x * 4;
+    for (; i < n; i += stride) {
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        if (accumulate) load4(out + i, a);
+        for (int s = 0; s < splits; ++s) {
+            float v[4]; load4(slab + (long)s * n + i, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += v[e];
+        }
+        store4(out + i, a);
     }
 }
 
@@ -227,7 +335,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     if (!bks) SCONF_REQUIRE(K % 8 == 0, "sconf_gemm_bf16: K must be a multiple of 8 for K-contiguous B");
     else      SCONF_REQUIRE(N % 8 == 0, "sconf_gemm_bf16: N must be a multiple of 8 for K-strided B");
     SCONF_REQUIRE(split_k >= 1, "sconf_gemm_bf16: split_k must be >= 1");
-    SCONF_REQUIRE(split_k == 1 || out_f32, "sconf_gemm_bf16: split-K accumulates with f32 atomics and needs out_f32");
+    SCONF_REQUIRE(split_k == 1 || out_f32, "sconf_gemm_bf16: split-K writes f32 partial slabs and needs out_f32");
     if (act == SCONF_ACT_DGELU || act == SCONF_ACT_DSILU) SCONF_REQUIRE(aux != nullptr, "sconf_gemm_bf16: dact epilogue needs aux");
 
     GemmParams p;
@@ -235,24 +343,57 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.resid = resid; p.ldr = ldr; p.aux = (const bf16*)aux; p.ldaux = ldaux;
     p.pre = (bf16*)pre; p.ldpre = ldpre; p.alpha = alpha; p.act = act; p.out_f32 = out_f32;
-    p.atomic = split_k > 1 ? 1 : 0;
     const int nkt = cdiv(K, BK);
     p.k_per_split = cdiv(nkt, split_k) * BK;
     const int splits = cdiv(K, p.k_per_split);
-    if (p.atomic) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
+    p.splits = splits;
+    p.split_stride = splits > 1 ? M * ldc : 0;
+    if (splits > 1) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
 
-    dim3 grid(cdiv(M, BM) * cdiv(N, BN), splits), block(256);
+    const int ntiles = cdiv(M, BM) * cdiv(N, BN);
+    dim3 grid(ntiles * splits), block(256);
     const size_t shmem = 4 * TILE_BYTES;
     static bool attr_set = false;
+    static bool no_glds = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        const void* fns[6] = {(const void*)gemm_kernel<false, false, false>, (const void*)gemm_kernel<false, true, false>,
+                              (const void*)gemm_kernel<true, true, false>, (const void*)gemm_kernel<false, false, true>,
+                              (const void*)gemm_kernel<false, true, true>, (const void*)gemm_kernel<true, true, true>};
+        for (int i = 0; i < 6; ++i) (void)hipFuncSetAttribute(fns[i], hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        no_glds = getenv("SCONF_GEMM_NO_GLDS") != nullptr;      // A/B switch for benchmarking the two staging paths
         attr_set = true;
     }
-    if (layout == 0)      hipLaunchKernelGGL((gemm_kernel<false, false>), grid, block, shmem, stream, p);
-    else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, block, shmem, stream, p);
-    else                  hipLaunchKernelGGL((gemm_kernel<true, true>), grid, block, shmem, stream, p);
+    // LDS-DMA staging needs whole 64-deep K tiles (no zero fill) and at least one full 8-row chunk to clamp to.
+    const bool glds = !no_glds && K % BK == 0 && M >= 8 && N >= 8;
+    if (glds) {
+        static int slots = 0;
+        if (!slots) { int n = sconf_num_cus(); slots = 2 * (n > 0 ? n : 256); }
+        grid.x = std::min(ntiles * splits, slots);                // persistent: <= 2 resident workgroups per CU
+        if (layout == 0)      hipLaunchKernelGGL((gemm_kernel<false, false, true>), grid, block, shmem, stream, p);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<false, true, true>), grid, block, shmem, stream, p);
+        else                  hipLaunchKernelGGL((gemm_kernel<true, true, true>), grid, block, shmem, stream, p);
+    } else {
+        if (layout == 0)      hipLaunchKernelGGL((gemm_kernel<false, false, false>), grid, block, shmem, stream, p);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_kernel<false, true, false>), grid, block, shmem, stream, p);
+        else                  hipLaunchKernelGGL((gemm_kernel<true, true, false>), grid, block, shmem, stream, p);
+    }
     SCONF_LAUNCH_OK("sconf_gemm_bf16");
+    return 0;
+}
+
+// Number of K-splits sconf_gemm_bf16 will actually use for (K, split_k): the caller sizes the slab buffer with it.
+SCONF_API int sconf_gemm_num_splits(int64_t K, int split_k) {
+    const int nkt = cdiv(K, BK);
+    const int kps = cdiv(nkt, split_k < 1 ? 1 : split_k) * BK;
+    return cdiv(K, kps);
+}
+
+// out[i] (+)= sum_s slab[s][i], i < n (n % 4 == 0): deterministic split-K combine (fixed summation order).
+SCONF_API int sconf_splitk_reduce(const float* slab, float* out, int64_t splits, int64_t n, int accumulate, hipStream_t stream) {
+    SCONF_REQUIRE(n % 4 == 0, "sconf_splitk_reduce: n must be a multiple of 4");
+    if (n == 0) return 0;
+    const int blocks = (int)std::min<long>(cdiv(n, 1024), 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slab, out, (int)splits, (long)n, accumulate);
+    SCONF_LAUNCH_OK("sconf_splitk_reduce");
     return 0;
 }

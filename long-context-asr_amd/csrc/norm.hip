@@ -7,7 +7,8 @@
 // The backward optionally adds a residual-stream gradient (`dres`) so that the pre-norm pattern
 //   x -> x + f(norm(x))     (wrappers.py:5-28, sconformer_xl.py:355-369)
 // needs a single pass: dx = dres + norm_bwd(dy).  Parameter gradients are reduced per lane over a
-// grid-stride loop of rows and flushed with one f32 atomic per column per wave.
+// grid-stride loop of rows, reduced across the workgroup's waves in LDS and flushed with one f32 atomic per
+// column per workgroup.
 #include "common.h"
 
 namespace {
@@ -129,14 +130,27 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
             }
         }
     }
+    // cross-wave reduction in LDS, then ONE atomic per column per workgroup (<= 512 workgroups): column atomics from
+    // every wave of every workgroup serialise on the few hundred addresses of dw/db.
+    __shared__ float red[4][256];
+    const int wvi = threadIdx.x >> 6;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
+        if (it * 256 >= d) break;                                   // uniform
         const int c = it * 256 + lane * 4;
-        if (c < d) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                atomicAdd(dw + c + e, aw[it][e]);
-                if (MODE == 0 && db) atomicAdd(db + c + e, ab[it][e]);
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass == 1 && !(MODE == 0 && db)) break;             // uniform
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[wvi][lane * 4 + e] = pass == 0 ? aw[it][e] : ab[it][e];
+            __syncthreads();
+            if (wvi == 0 && c < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float v = red[0][lane * 4 + e] + red[1][lane * 4 + e] + red[2][lane * 4 + e] + red[3][lane * 4 + e];
+                    atomicAdd((pass == 0 ? dw : db) + c + e, v);
+                }
             }
         }
     }
@@ -158,7 +172,7 @@ int launch_fwd(const void* x, int xdt, const float* w, const float* b, void* y, 
 template <int MODE>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
                const float* dres, void* dx, int odt, float* dw, float* db, int M, int d, float eps, hipStream_t st) {
-    dim3 grid(min(cdiv(M, 4), 1024)), block(256);
+    dim3 grid(min(cdiv(M, 4), 512)), block(256);
 #define L(TI, TG, TO) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, M, d, eps)
     if (xdt == SCONF_F32) {
         if (gdt == SCONF_F32) { if (odt == SCONF_F32) L(float, float, float); else L(float, float, bf16); }

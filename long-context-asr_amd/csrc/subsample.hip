@@ -14,75 +14,113 @@ namespace {
 
 constexpr int CG8 = 8;                               // channels per thread (16-B bf16 accesses)
 
+// Thread geometry shared by the conv kernels: a thread OWNS one group of 8 channels for its whole life (its 72 filter
+// taps + bias sit in registers) and walks output positions; a workgroup = cgs channel groups x PL position lanes, so
+// each iteration touches PL x (C*2) contiguous bytes.  blockIdx.y = batch item; all index math is 32-bit.
+struct Geo {
+    int cg, plane, c0;
+    bool active;
+    __device__ __forceinline__ Geo(int C, int PL) {
+        const int cgs = C / CG8;
+        cg = threadIdx.x % cgs; plane = threadIdx.x / cgs; c0 = cg * CG8;
+        active = plane < PL;
+    }
+};
+
 // ---- conv0: Conv2d(1 -> C, 3x3, stride 2, pad 1) + bias, pre-activation out -----------------
 template <typename TX>
 __global__ __launch_bounds__(256) void conv0_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w,
                                                         const float* __restrict__ bias, bf16* __restrict__ y,
-                                                        int B, int F, int T, int C, int T2, int F2) {
-    const int cgs = C / CG8;
-    const long total = (long)B * T2 * F2 * cgs;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c0 = (int)(idx % cgs) * CG8;
-        const long pos = idx / cgs;
-        const int f2 = (int)(pos % F2), t2 = (int)((pos / F2) % T2), b = (int)(pos / ((long)F2 * T2));
+                                                        int F, int T, int C, int T2, int F2, int PL, int iters) {
+    const Geo g(C, PL);
+    if (!g.active) return;
+    const int b = blockIdx.y, npos = T2 * F2;
+    float wk[9][8], bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = bias[g.c0 + e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k][e] = w[(g.c0 + e) * 9 + k]; }
+    const TX* xb = x + (long)b * F * T;
+    bf16* yb = y + (long)b * npos * C;
+    for (int it = 0; it < iters; ++it) {
+        const int p = (blockIdx.x * iters + it) * PL + g.plane;
+        if (p >= npos) break;
+        const int t2 = p / F2, f2 = p - t2 * F2;
         float in[9];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = 2 * t2 + i - 1, f = 2 * f2 + j - 1;
-                in[i * 3 + j] = (t >= 0 && t < T && f >= 0 && f < F) ? ld_f(x + ((long)b * F + f) * T + t) : 0.f;
+                in[i * 3 + j] = (t >= 0 && t < T && f >= 0 && f < F) ? ld_f(xb + (long)f * T + t) : 0.f;
             }
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            float acc = bias[c0 + e];
+            float acc = bs[e];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) acc += w[(c0 + e) * 9 + k] * in[k];
+            for (int k = 0; k < 9; ++k) acc += wk[k][e] * in[k];
             o[e] = acc;
         }
-        store8(y + pos * C + c0, o);
+        store8(yb + (long)p * C + g.c0, o);
     }
 }
 
 // ---- depthwise Conv2d(C, 3x3, stride 2, pad 1, groups=C) + bias on SiLU(in) ------------------
 __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, bf16* __restrict__ y,
-                                                           int B, int Ti, int Fi, int C, int To, int Fo) {
-    const int cgs = C / CG8;
-    const long total = (long)B * To * Fo * cgs;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c0 = (int)(idx % cgs) * CG8;
-        const long pos = idx / cgs;
-        const int fo = (int)(pos % Fo), to = (int)((pos / Fo) % To), b = (int)(pos / ((long)Fo * To));
+                                                           int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
+    const Geo g(C, PL);
+    if (!g.active) return;
+    const int b = blockIdx.y, npos = To * Fo;
+    float wk[9][8], bs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { bs[e] = bias[g.c0 + e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k][e] = w[(g.c0 + e) * 9 + k]; }
+    const bf16* xb = x + (long)b * Ti * Fi * C + g.c0;
+    bf16* yb = y + (long)b * npos * C + g.c0;
+    for (int it = 0; it < iters; ++it) {
+        const int p = (blockIdx.x * iters + it) * PL + g.plane;
+        if (p >= npos) break;
+        const int to = p / Fo, fo = p - to * Fo;
         float acc[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = bias[c0 + e];
+        for (int e = 0; e < 8; ++e) acc[e] = bs[e];
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = 2 * to + i - 1, f = 2 * fo + j - 1;
                 if (t >= 0 && t < Ti && f >= 0 && f < Fi) {
-                    float v[8]; load8(x + (((long)b * Ti + t) * Fi + f) * C + c0, v);
+                    float v[8]; load8(xb + ((long)t * Fi + f) * C, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += w[(c0 + e) * 9 + i * 3 + j] * siluf_(v[e]);
+                    for (int e = 0; e < 8; ++e) acc[e] += wk[i * 3 + j][e] * siluf_(v[e]);
                 }
             }
-        store8(y + pos * C + c0, acc);
+        store8(yb + (long)p * C, acc);
     }
 }
 
 // ---- input gradient of the depthwise conv, times SiLU'(pre_in) ------------------------------
 __global__ __launch_bounds__(256) void dwconv2d_bwd_input_kernel(const bf16* __restrict__ dout, const float* __restrict__ w,
                                                                  const bf16* __restrict__ pre_in, bf16* __restrict__ dpre_in,
-                                                                 int B, int Ti, int Fi, int C, int To, int Fo) {
-    const int cgs = C / CG8;
-    const long total = (long)B * Ti * Fi * cgs;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-        const int c0 = (int)(idx % cgs) * CG8;
-        const long pos = idx / cgs;
-        const int fi = (int)(pos % Fi), ti = (int)((pos / Fi) % Ti), b = (int)(pos / ((long)Fi * Ti));
+                                                                 int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
+    const Geo g(C, PL);
+    if (!g.active) return;
+    const int b = blockIdx.y, npos = Ti * Fi;
+    float wk[9][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wk[k][e] = w[(g.c0 + e) * 9 + k];
+    const bf16* gb = dout + (long)b * To * Fo * C + g.c0;
+    const bf16* pb = pre_in + (long)b * npos * C + g.c0;
+    bf16* ob = dpre_in + (long)b * npos * C + g.c0;
+    for (int it = 0; it < iters; ++it) {
+        const int p = (blockIdx.x * iters + it) * PL + g.plane;
+        if (p >= npos) break;
+        const int ti = p / Fi, fi = p - ti * Fi;
         float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -96,64 +134,77 @@ __global__ __launch_bounds__(256) void dwconv2d_bwd_input_kernel(const bf16* __r
                 if (ff < 0 || (ff & 1)) continue;
                 const int fo = ff >> 1;
                 if (fo >= Fo) continue;
-                float g[8]; load8(dout + (((long)b * To + to) * Fo + fo) * C + c0, g);
+                float gv[8]; load8(gb + ((long)to * Fo + fo) * C, gv);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += w[(c0 + e) * 9 + i * 3 + j] * g[e];
+                for (int e = 0; e < 8; ++e) acc[e] += wk[i * 3 + j][e] * gv[e];
             }
         }
-        float p[8]; load8(pre_in + pos * C + c0, p);
+        float pv[8]; load8(pb + (long)p * C, pv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= dsiluf_(p[e]);
-        store8(dpre_in + pos * C + c0, acc);
+        for (int e = 0; e < 8; ++e) acc[e] *= dsiluf_(pv[e]);
+        store8(ob + (long)p * C, acc);
     }
 }
 
 // ---- weight / bias gradients of a 3x3 stride-2 conv whose output gradient is channels-last -----
 // DEPTHWISE: input is SiLU(pre_in[.., c]); otherwise (conv0) the single-channel mel input (B,F,T).
+// Each thread accumulates its channel group's 72+8 sums over its positions in registers; the workgroup then reduces
+// across its position lanes through LDS and issues ONE atomic per sum (a few hundred workgroups in total), because
+// per-thread atomics on the ~C*10 distinct addresses serialise.
 template <bool DEPTHWISE, typename TX>
 __global__ __launch_bounds__(256) void conv3x3s2_bwd_weight_kernel(const bf16* __restrict__ dout, const void* __restrict__ in_,
                                                                    float* __restrict__ dw, float* __restrict__ dbias,
-                                                                   int B, int Ti, int Fi, int C, int To, int Fo, int strip) {
+                                                                   int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
+    __shared__ float red[256];
+    const Geo g(C, PL);
     const int cgs = C / CG8;
-    const long npos = (long)B * To * Fo;
-    const long nstrips = (npos + strip - 1) / strip;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= nstrips * cgs) return;
-    const int c0 = (int)(idx % cgs) * CG8;
-    const long p0 = (idx / cgs) * strip, p1 = min(npos, p0 + strip);
-    float gw[9][8], gb[8];
+    const int b = blockIdx.y, npos = To * Fo;
+    float gw[9][8], gbs[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { gb[e] = 0.f;
+    for (int e = 0; e < 8; ++e) { gbs[e] = 0.f;
 #pragma unroll
         for (int k = 0; k < 9; ++k) gw[k][e] = 0.f; }
-    for (long pos = p0; pos < p1; ++pos) {
-        const int fo = (int)(pos % Fo), to = (int)((pos / Fo) % To), b = (int)(pos / ((long)Fo * To));
-        float g[8]; load8(dout + pos * C + c0, g);
+    const bf16* gp = dout + (long)b * npos * C + g.c0;
+    if (g.active) {
+        for (int it = 0; it < iters; ++it) {
+            const int p = (blockIdx.x * iters + it) * PL + g.plane;
+            if (p >= npos) break;
+            const int to = p / Fo, fo = p - to * Fo;
+            float gv[8]; load8(gp + (long)p * C, gv);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) gb[e] += g[e];
+            for (int e = 0; e < 8; ++e) gbs[e] += gv[e];
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
+            for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int t = 2 * to + i - 1, f = 2 * fo + j - 1;
-                if (t < 0 || t >= Ti || f < 0 || f >= Fi) continue;
-                if (DEPTHWISE) {
-                    float v[8]; load8((const bf16*)in_ + (((long)b * Ti + t) * Fi + f) * C + c0, v);
+                for (int j = 0; j < 3; ++j) {
+                    const int t = 2 * to + i - 1, f = 2 * fo + j - 1;
+                    if (t < 0 || t >= Ti || f < 0 || f >= Fi) continue;
+                    if (DEPTHWISE) {
+                        float v[8]; load8((const bf16*)in_ + (((long)b * Ti + t) * Fi + f) * C + g.c0, v);
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gw[i * 3 + j][e] += g[e] * siluf_(v[e]);
-                } else {
-                    const float v = ld_f((const TX*)in_ + ((long)b * Fi + f) * Ti + t);   // mel is (B,F,T)
+                        for (int e = 0; e < 8; ++e) gw[i * 3 + j][e] += gv[e] * siluf_(v[e]);
+                    } else {
+                        const float v = ld_f((const TX*)in_ + ((long)b * Fi + f) * Ti + t);   // mel is (B,F,T)
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) gw[i * 3 + j][e] += g[e] * v;
+                        for (int e = 0; e < 8; ++e) gw[i * 3 + j][e] += gv[e] * v;
+                    }
                 }
+        }
+    }
+    // workgroup reduction over position lanes, one value at a time (80 values per channel group)
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            __syncthreads();
+            red[threadIdx.x] = g.active ? (k < 9 ? gw[k][e] : gbs[e]) : 0.f;
+            __syncthreads();
+            if (g.plane == 0) {
+                float v = 0.f;
+                for (int pl = 0; pl < PL; ++pl) v += red[pl * cgs + g.cg];
+                if (k < 9) atomicAdd(dw + (g.c0 + e) * 9 + k, v); else atomicAdd(dbias + g.c0 + e, v);
             }
-    }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        atomicAdd(dbias + c0 + e, gb[e]);
-#pragma unroll
-        for (int k = 0; k < 9; ++k) atomicAdd(dw + (c0 + e) * 9 + k, gw[k][e]);
-    }
+        }
 }
 
 // ---- SiLU + (F8, C) -> (C, F8) transpose of one token's features, through LDS ------------------
@@ -194,7 +245,20 @@ __global__ __launch_bounds__(256) void silu_transpose_kernel(const bf16* __restr
     }
 }
 
-inline int grid_for(long total_threads) { return (int)std::min<long>(cdiv(total_threads, 256), 16384); }
+struct LaunchGeo { int PL, iters, threads; dim3 grid; };
+// npos positions per batch item; aim for ~target workgroups in total.
+inline LaunchGeo geo_for(int64_t C, int64_t B, long npos, long target_blocks) {
+    LaunchGeo g;
+    const int cgs = (int)(C / 8);
+    g.PL = std::max(1, 256 / cgs);
+    g.threads = (cgs * g.PL + 63) / 64 * 64;
+    const long per_b = std::max<long>(1, target_blocks / B);
+    g.iters = (int)std::max<long>(1, cdiv(npos, (long)g.PL * per_b));
+    g.grid = dim3(cdiv(npos, (long)g.PL * g.iters), (unsigned)B);
+    return g;
+}
+#define SUB_REQ(fn) SCONF_REQUIRE(C % 8 == 0 && C / 8 <= 256, fn ": C must be a multiple of 8 and <= 2048"); \
+                    SCONF_REQUIRE(B <= 65535, fn ": B must be <= 65535")
 
 }  // namespace
 
@@ -202,12 +266,12 @@ inline int grid_for(long total_threads) { return (int)std::min<long>(cdiv(total_
 // Replaces subsampling.py:299-306 (self.conv[0]); SiLU (conv[1]) is applied by the consumer.
 SCONF_API int sconf_sub_conv0_fwd(const void* x, int x_dtype, const float* w, const float* bias, void* y,
                                   int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream) {
-    SCONF_REQUIRE(C % 8 == 0, "sconf_sub_conv0_fwd: C must be a multiple of 8");
+    SUB_REQ("sconf_sub_conv0_fwd");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1);
-    const long total = B * T2 * F2 * (C / 8);
-    if (total == 0) return 0;
-    if (x_dtype == SCONF_F32) hipLaunchKernelGGL((conv0_fwd_kernel<float>), dim3(grid_for(total)), dim3(256), 0, stream, (const float*)x, w, bias, (bf16*)y, (int)B, (int)F, (int)T, (int)C, T2, F2);
-    else hipLaunchKernelGGL((conv0_fwd_kernel<bf16>), dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, (int)B, (int)F, (int)T, (int)C, T2, F2);
+    if (B * T2 * F2 == 0) return 0;
+    const LaunchGeo g = geo_for(C, B, (long)T2 * F2, 16384);
+    if (x_dtype == SCONF_F32) hipLaunchKernelGGL((conv0_fwd_kernel<float>), g.grid, dim3(g.threads), 0, stream, (const float*)x, w, bias, (bf16*)y, (int)F, (int)T, (int)C, T2, F2, g.PL, g.iters);
+    else hipLaunchKernelGGL((conv0_fwd_kernel<bf16>), g.grid, dim3(g.threads), 0, stream, (const bf16*)x, w, bias, (bf16*)y, (int)F, (int)T, (int)C, T2, F2, g.PL, g.iters);
     SCONF_LAUNCH_OK("sconf_sub_conv0_fwd");
     return 0;
 }
@@ -216,11 +280,11 @@ SCONF_API int sconf_sub_conv0_fwd(const void* x, int x_dtype, const float* w, co
 // the preceding activation (conv[1], conv[4]).
 SCONF_API int sconf_sub_dwconv_fwd(const void* x, const float* w, const float* bias, void* y,
                                    int64_t B, int64_t Ti, int64_t Fi, int64_t C, hipStream_t stream) {
-    SCONF_REQUIRE(C % 8 == 0, "sconf_sub_dwconv_fwd: C must be a multiple of 8");
+    SUB_REQ("sconf_sub_dwconv_fwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
-    const long total = B * To * Fo * (C / 8);
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(dwconv2d_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)x, w, bias, (bf16*)y, (int)B, (int)Ti, (int)Fi, (int)C, To, Fo);
+    if (B * To * Fo == 0) return 0;
+    const LaunchGeo g = geo_for(C, B, (long)To * Fo, 16384);
+    hipLaunchKernelGGL(dwconv2d_fwd_kernel, g.grid, dim3(g.threads), 0, stream, (const bf16*)x, w, bias, (bf16*)y, (int)Ti, (int)Fi, (int)C, To, Fo, g.PL, g.iters);
     SCONF_LAUNCH_OK("sconf_sub_dwconv_fwd");
     return 0;
 }
@@ -228,16 +292,13 @@ SCONF_API int sconf_sub_dwconv_fwd(const void* x, const float* w, const float* b
 // dpre_in = SiLU'(pre_in) * dwconv^T(dout);  dw/dbias ACCUMULATED (+=).
 SCONF_API int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void* pre_in, void* dpre_in, float* dw, float* dbias,
                                    int64_t B, int64_t Ti, int64_t Fi, int64_t C, hipStream_t stream) {
-    SCONF_REQUIRE(C % 8 == 0, "sconf_sub_dwconv_bwd: C must be a multiple of 8");
+    SUB_REQ("sconf_sub_dwconv_bwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
-    const long total = B * Ti * Fi * (C / 8);
-    if (total == 0) return 0;
-    hipLaunchKernelGGL(dwconv2d_bwd_input_kernel, dim3(grid_for(total)), dim3(256), 0, stream, (const bf16*)dout, w, (const bf16*)pre_in, (bf16*)dpre_in, (int)B, (int)Ti, (int)Fi, (int)C, To, Fo);
-    const long npos = B * To * Fo;
-    int strip = 64;
-    while (strip > 4 && cdiv(npos, strip) * (C / 8) < 65536) strip >>= 1;
-    const long threads = cdiv(npos, strip) * (C / 8);
-    hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<true, float>), dim3(cdiv(threads, 256)), dim3(256), 0, stream, (const bf16*)dout, pre_in, dw, dbias, (int)B, (int)Ti, (int)Fi, (int)C, To, Fo, strip);
+    if (B * Ti * Fi == 0) return 0;
+    const LaunchGeo gi = geo_for(C, B, (long)Ti * Fi, 16384);
+    hipLaunchKernelGGL(dwconv2d_bwd_input_kernel, gi.grid, dim3(gi.threads), 0, stream, (const bf16*)dout, w, (const bf16*)pre_in, (bf16*)dpre_in, (int)Ti, (int)Fi, (int)C, To, Fo, gi.PL, gi.iters);
+    const LaunchGeo gw = geo_for(C, B, (long)To * Fo, 1024);
+    hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<true, float>), gw.grid, dim3(gw.threads), 0, stream, (const bf16*)dout, pre_in, dw, dbias, (int)Ti, (int)Fi, (int)C, To, Fo, gw.PL, gw.iters);
     SCONF_LAUNCH_OK("sconf_sub_dwconv_bwd");
     return 0;
 }
@@ -245,15 +306,12 @@ SCONF_API int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void*
 // conv0 parameter gradients (the mel input needs no gradient).  dw [C][9], dbias [C] ACCUMULATED (+=).
 SCONF_API int sconf_sub_conv0_bwd(const void* dpre0, const void* x, int x_dtype, float* dw, float* dbias,
                                   int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream) {
-    SCONF_REQUIRE(C % 8 == 0, "sconf_sub_conv0_bwd: C must be a multiple of 8");
+    SUB_REQ("sconf_sub_conv0_bwd");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1);
-    const long npos = B * T2 * F2;
-    if (npos == 0) return 0;
-    int strip = 64;
-    while (strip > 4 && cdiv(npos, strip) * (C / 8) < 65536) strip >>= 1;
-    const long threads = cdiv(npos, strip) * (C / 8);
-    if (x_dtype == SCONF_F32) hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<false, float>), dim3(cdiv(threads, 256)), dim3(256), 0, stream, (const bf16*)dpre0, x, dw, dbias, (int)B, (int)T, (int)F, (int)C, T2, F2, strip);
-    else hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<false, bf16>), dim3(cdiv(threads, 256)), dim3(256), 0, stream, (const bf16*)dpre0, x, dw, dbias, (int)B, (int)T, (int)F, (int)C, T2, F2, strip);
+    if (B * T2 * F2 == 0) return 0;
+    const LaunchGeo g = geo_for(C, B, (long)T2 * F2, 1024);
+    if (x_dtype == SCONF_F32) hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<false, float>), g.grid, dim3(g.threads), 0, stream, (const bf16*)dpre0, x, dw, dbias, (int)T, (int)F, (int)C, T2, F2, g.PL, g.iters);
+    else hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<false, bf16>), g.grid, dim3(g.threads), 0, stream, (const bf16*)dpre0, x, dw, dbias, (int)T, (int)F, (int)C, T2, F2, g.PL, g.iters);
     SCONF_LAUNCH_OK("sconf_sub_conv0_bwd");
     return 0;
 }

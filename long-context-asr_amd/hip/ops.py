@@ -77,8 +77,9 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
     if K != K2:
         raise ValueError(f'gemm {layout}: inner dims differ: {tuple(a.shape)} x {tuple(b.shape)}')
     out_f32 = out_dtype == torch.float32
-    if split_k > 1:
-        c = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+    splits = _lib.load().sconf_gemm_num_splits(K, int(split_k)) if split_k > 1 else 1
+    if splits > 1:                                                     # deterministic split-K: partial slabs + fixed-order reduce
+        c = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
     else:
         c = torch.empty(M, N, dtype=out_dtype, device=a.device)
     pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if save_pre else None
@@ -91,15 +92,30 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
         if tuple(aux.shape) != (M, N): raise ValueError('aux shape mismatch')
     _lib.call('sconf_gemm_bf16', LAYOUT[layout], _p(a), _p(b), _p(c), M, N, K, a.stride(0), b.stride(0), N,
               _p(bias), _p(resid), N, _p(aux), N, _p(pre), N, float(alpha), ACT[act], int(out_f32), int(split_k), _stream())
+    if splits > 1:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        _lib.call('sconf_splitk_reduce', _p(c), _p(out), splits, M * N, 0, _stream())
+        c = out
     return (c, pre) if save_pre else c
 
 
 def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
-    """Split-K factor for weight-gradient GEMMs (few output tiles, very long K)."""
+    """Split-K factor for weight-gradient GEMMs (few output tiles, very long K).
+
+    The GEMM runs at most 2 persistent workgroups per CU (`slots`) that walk the tiles x s work items, each item being
+    ceil(nkt / s) K-steps plus an epilogue of f32 atomics worth ~3 K-steps.  Pick the s that minimises the critical path."""
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
-    if tiles >= 2 * n_cus or K <= 2048:
+    nkt = (K + 63) // 64
+    slots = 2 * n_cus
+    if tiles >= slots or nkt < 32:
         return 1
-    return int(max(1, min(K // 1024, (2 * n_cus + tiles - 1) // tiles, 16)))
+    best, best_cost = 1, None
+    for s_ in range(1, min(32, nkt // 8) + 1):
+        items = tiles * s_                                   # (tile, split) work items, walked by <= slots workgroups
+        cost = -(-items // min(items, slots)) * (-(-nkt // s_) + (3 if s_ > 1 else 1))
+        if best_cost is None or cost < best_cost:
+            best, best_cost = s_, cost
+    return best
 
 
 # ------------------------------------------------------------------------------------------------
