@@ -65,18 +65,56 @@ template <int D, int ROWS> struct Stage {
     }
 };
 
-// A operand, row form: A[row = rbase + lane&31][k = 16*st + 8*hh + j]
-template <int D> __device__ __forceinline__ bf16x8 frag_row(const char* s, int rbase, int st, int lane) {
-    return *reinterpret_cast<const bf16x8*>(s + tile_off<D>(rbase + (lane & 31), 2 * st + (lane >> 5)));
+// ---- LDS-DMA staging of a [ROWS][D] bf16 tile (global_load_lds_dwordx4): no staging VGPRs, no ds_write, no guards --
+// LDS destination is linear (wave base + lane*16), so the tile_off swizzle is applied to the per-lane SOURCE chunk and
+// undone by the same XOR on the fragment reads.  Rows beyond the tensor are clamped to its last row: their scores are
+// masked (keys) or their LSE is +inf (queries), so the duplicated finite data never reaches an output.
+template <int D, int ROWS>
+__device__ __forceinline__ void glds_tile(const bf16* base, long sn, int row0, int nrows_valid, char* lds, int tid) {
+    constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = (CHUNKS + 255) / 256;
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 256 * i;
+        if (CHUNKS % 256 == 0 || c < CHUNKS) {
+            const int row = c / CPR, pos = c % CPR;
+            const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+            const int gr = min(row0 + row, nrows_valid - 1);
+            __builtin_amdgcn_global_load_lds((gptr)(base + (long)gr * sn + (pos ^ swz) * 8), (lptr)(lds + ((tid & ~63) + 256 * i) * 16), 16, 0, 0);
+        }
+    }
 }
-// A operand, transposed form: A[row = tile column cbase + lane&31][k-slot j] where slot j of lane half hh is
-// tile row  rb + 8*(j>>2) + 4*hh + (j&3)  — the k order of a packed 32x32 accumulator (B operand).
-template <int D> __device__ __forceinline__ bf16x8 frag_tr(const char* s, int rb, int cbase, int lane) {
-    const int i = lane & 15, q4 = i >> 2, p4 = i & 3, G = (lane >> 4) & 1, hh = lane >> 5;
-    const int row0 = rb + 4 * hh + q4, ch = (cbase >> 3) + 2 * G + (p4 >> 1), sub = (p4 & 1) * 8;
+
+// Loop-invariant per-lane LDS byte offsets.  tile_off's swizzle depends only on (row & 3) and ((row >> 2) & 3), so a
+// row base that is a multiple of 16 adds linearly (rbase * 2D) and every fragment read is "lane offset + constant":
+// the address math leaves the inner loops (it was ~8 VALU ops per ds_read, several hundred per MFMA block).
+template <int D> struct LaneOffs {
+    int row[D / 16];                 // row form, k-step st
+    int trlo[D / 32], trhi[D / 32];  // transposed form, column block db (rows rb+4hh+q4 and +8)
+    __device__ __forceinline__ LaneOffs(int lane) {
+#pragma unroll
+        for (int st = 0; st < D / 16; ++st) row[st] = tile_off<D>(lane & 31, 2 * st + (lane >> 5));
+        const int i = lane & 15, q4 = i >> 2, p4 = i & 3, G = (lane >> 4) & 1, hh = lane >> 5;
+        const int row0 = 4 * hh + q4, sub = (p4 & 1) * 8;
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db) {
+            const int ch = db * 4 + 2 * G + (p4 >> 1);
+            trlo[db] = tile_off<D>(row0, ch) + sub;
+            trhi[db] = tile_off<D>(row0 + 8, ch) + sub;
+        }
+    }
+};
+// A operand, row form: A[row = rbase + lane&31][k = 16*st + 8*hh + j]          (rbase % 16 == 0)
+template <int D> __device__ __forceinline__ bf16x8 frag_row(const char* s, const LaneOffs<D>& L, int rbase, int st) {
+    return *reinterpret_cast<const bf16x8*>(s + rbase * 2 * D + L.row[st]);
+}
+// A operand, transposed form: A[row = tile column db*32 + lane&31][k-slot j] where slot j of lane half hh is
+// tile row  rb + 8*(j>>2) + 4*hh + (j&3)  — the k order of a packed 32x32 accumulator (B operand).   (rb % 16 == 0)
+template <int D> __device__ __forceinline__ bf16x8 frag_tr(const char* s, const LaneOffs<D>& L, int rb, int db) {
     typedef __attribute__((address_space(3))) bf16x4* lds_p;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + tile_off<D>(row0, ch) + sub));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + tile_off<D>(row0 + 8, ch) + sub));
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + rb * 2 * D + L.trlo[db]));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + rb * 2 * D + L.trhi[db]));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // B operand straight from global: B[k = 16*st + 8*hh + j][col = lane&31] = X[row0 + lane&31][d]
@@ -128,6 +166,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 
     bf16x8 qf[D / 16];
     load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+    const LaneOffs<D> L(lane);
 
     const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
     const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 128 + p.win_right);
@@ -141,17 +180,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    Stage<D, 64> sk, sv;
-    if (t_lo < t_hi) {
-        sk.gload(kp, p.k_sn, t_lo * 64, p.N, tid); sv.gload(vp, p.v_sn, t_lo * 64, p.N, tid);
-        sk.lstore(smem, tid); sv.lstore(smem + TB, tid);
-    }
+    if (t_lo < t_hi) { glds_tile<D, 64>(kp, p.k_sn, t_lo * 64, p.N, smem, tid); glds_tile<D, 64>(vp, p.v_sn, t_lo * 64, p.N, smem + TB, tid); }
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sK = smem + cur * 2 * TB;
         const char* sV = sK + TB;
-        if (t + 1 < t_hi) { sk.gload(kp, p.k_sn, (t + 1) * 64, p.N, tid); sv.gload(vp, p.v_sn, (t + 1) * 64, p.N, tid); }
+        if (t + 1 < t_hi) {                                  // next K/V tile streams into the other buffer during this tile
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            glds_tile<D, 64>(kp, p.k_sn, (t + 1) * 64, p.N, dK, tid); glds_tile<D, 64>(vp, p.v_sn, (t + 1) * 64, p.N, dK + TB, tid);
+        }
         const int kv0 = t * 64;
         f32x16 s[2];
 #pragma unroll
@@ -160,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
 #pragma unroll
             for (int st = 0; st < D / 16; ++st)
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kt * 32, st, lane), qf[st], s[kt], 0, 0, 0);
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, L, kt * 32, st), qf[st], s[kt], 0, 0, 0);
         }
         if (kv0 + 64 > kv_hi || windowed) {
 #pragma unroll
@@ -204,11 +242,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sV, kt * 32 + 16 * s2, db * 32, lane), pf[kt][s2], o[db], 0, 0, 0);
-        if (t + 1 < t_hi) {
-            char* dK = smem + (cur ^ 1) * 2 * TB;
-            sk.lstore(dK, tid); sv.lstore(dK + TB, tid);
-        }
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sV, L, kt * 32 + 16 * s2, db), pf[kt][s2], o[db], 0, 0, 0);
         __syncthreads();
     }
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -247,7 +281,7 @@ __global__ void attn_delta_kernel(const AttnParams p) {
 // backward dK/dV: grid (ceil(N/128), H, B); each wave owns 32 keys, sweeps 32-row query tiles
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 32 * 2 * D;                     // Q tile / dO tile bytes (32 rows)
     constexpr int SB = 2 * TB + 256;                   // one stage: Q | dO | lse2[32] | delta[32]
@@ -263,9 +297,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams 
     const int key = k0 + (lane & 31);
     const float c = p.scale * 1.4426950408889634f;
 
-    bf16x8 kf[D / 16], vf[D / 16];
+    bf16x8 kf[D / 16];
     load_bfrags<D>(kf, kp, p.k_sn, k0, p.N, lane);
-    load_bfrags<D>(vf, vp, p.v_sn, k0, p.N, lane);
+    const LaneOffs<D> L(lane);
+    // this workgroup's 128 V rows live in LDS for the whole kernel (B operand of dP = dO V^T, read per iteration):
+    // keeping them in registers next to K, dK^T and dV^T (64 + 128 VGPRs) spills into the loop.
+    char* sVt = smem + 2 * SB;
+    glds_tile<D, 128>(vp, p.v_sn, kb0, p.N, sVt, tid);
+    const char* sVw = sVt + wave * 32 * 2 * D;
+    const bool need_mask = p.win_left >= 0 || p.win_right >= 0 || kb0 + 128 > len;   // uniform per workgroup
 
     // queries that can see this block's keys: key in [q-left, q+right]  <=>  q in [key-right, key+left]
     const int q_lo = p.win_right < 0 ? 0 : max(0, kb0 - p.win_right);
@@ -278,7 +318,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams 
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
 
-    Stage<D, 32> sq, sg;
     float st_l = 0.f, st_d = 0.f;
     auto gload_stats = [&](int q0) {
         if (tid < 32) { const int q = q0 + tid; st_l = (q < len) ? lsep[q] * 1.4426950408889634f : INFINITY; st_d = (q < len) ? delp[q] : 0.f; }
@@ -287,8 +326,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams 
         if (tid < 32) { reinterpret_cast<float*>(s + 2 * TB)[tid] = st_l; reinterpret_cast<float*>(s + 2 * TB + 128)[tid] = st_d; }
     };
     if (t_lo < t_hi) {
-        sq.gload(qp, p.q_sn, t_lo * 32, p.N, tid); sg.gload(gp, p.do_sn, t_lo * 32, p.N, tid); gload_stats(t_lo * 32);
-        sq.lstore(smem, tid); sg.lstore(smem + TB, tid); lstore_stats(smem);
+        glds_tile<D, 32>(qp, p.q_sn, t_lo * 32, p.N, smem, tid); glds_tile<D, 32>(gp, p.do_sn, t_lo * 32, p.N, smem + TB, tid);
+        gload_stats(t_lo * 32); lstore_stats(smem);
     }
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
@@ -297,38 +336,64 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams 
         const char* sG = sQ + TB;
         const float* sL = reinterpret_cast<const float*>(sQ + 2 * TB);
         const float* sD = sL + 32;
-        if (t + 1 < t_hi) { sq.gload(qp, p.q_sn, (t + 1) * 32, p.N, tid); sg.gload(gp, p.do_sn, (t + 1) * 32, p.N, tid); gload_stats((t + 1) * 32); }
+        if (t + 1 < t_hi) {
+            char* dS = smem + (cur ^ 1) * SB;
+            glds_tile<D, 32>(qp, p.q_sn, (t + 1) * 32, p.N, dS, tid); glds_tile<D, 32>(gp, p.do_sn, (t + 1) * 32, p.N, dS + TB, tid);
+            gload_stats((t + 1) * 32);
+        }
         const int q0 = t * 32;
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
         for (int st = 0; st < D / 16; ++st) {
-            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, 0, st, lane), kf[st], s, 0, 0, 0);     // S[q][key]
-            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sG, 0, st, lane), vf[st], dp, 0, 0, 0);   // dP[q][key]
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, L, 0, st), kf[st], s, 0, 0, 0);     // S[q][key]
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sG, L, 0, st), frag_row<D>(sVw, L, 0, st), dp, 0, 0, 0);   // dP[q][key]
         }
+        // row statistics of this lane's 16 query rows: 4 consecutive rows per b128 read (rows 8g + 4hh + 0..3).
+        // Two straight-line bodies (mask-free / masked) chosen by ONE uniform branch.
+        if (!need_mask) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int qr = acc_row(r, hh), q = q0 + qr;
-            bool ok = key < len;
-            if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
-            if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
-            const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - sL[qr]) : 0.f;   // lse2 = +inf for q >= len
-            s[r] = pr;
-            dp[r] = pr * (dp[r] - sD[qr]);
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(sL + 8 * g + 4 * hh);
+                const float4 b_ = *reinterpret_cast<const float4*>(sD + 8 * g + 4 * hh);
+                const float la[4] = {a.x, a.y, a.z, a.w}, da[4] = {b_.x, b_.y, b_.z, b_.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const float pr = __builtin_amdgcn_exp2f(s[r] * c - la[e]);   // lse2 = +inf for q >= len -> 0
+                    s[r] = pr;
+                    dp[r] = pr * (dp[r] - da[e]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(sL + 8 * g + 4 * hh);
+                const float4 b_ = *reinterpret_cast<const float4*>(sD + 8 * g + 4 * hh);
+                const float la[4] = {a.x, a.y, a.z, a.w}, da[4] = {b_.x, b_.y, b_.z, b_.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int q = q0 + acc_row(r, hh);
+                    bool ok = key < len;
+                    if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
+                    if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
+                    const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - la[e]) : 0.f;
+                    s[r] = pr;
+                    dp[r] = pr * (dp[r] - da[e]);
+                }
+            }
         }
         const bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
 #pragma unroll
         for (int db = 0; db < D / 32; ++db) {
-            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, 0, db * 32, lane), pb0, dvt[db], 0, 0, 0);
-            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, 16, db * 32, lane), pb1, dvt[db], 0, 0, 0);
-            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, 0, db * 32, lane), db0, dkt[db], 0, 0, 0);
-            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, 16, db * 32, lane), db1, dkt[db], 0, 0, 0);
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, 0, db), pb0, dvt[db], 0, 0, 0);
+            dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, 16, db), pb1, dvt[db], 0, 0, 0);
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, 0, db), db0, dkt[db], 0, 0, 0);
+            dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, 16, db), db1, dkt[db], 0, 0, 0);
         }
-        if (t + 1 < t_hi) {
-            char* dS = smem + (cur ^ 1) * SB;
-            sq.lstore(dS, tid); sg.lstore(dS + TB, tid); lstore_stats(dS);
-        }
+        if (t + 1 < t_hi) lstore_stats(smem + (cur ^ 1) * SB);
         __syncthreads();
     }
     if (key < p.N) {
@@ -341,7 +406,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkdv_kernel(const AttnParams 
 // backward dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps 64-key tiles
 // =============================================================================================
 template <int D>
-__global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnParams p) {
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
@@ -359,6 +424,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnParams p)
     bf16x8 qf[D / 16], gf[D / 16];
     load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
     load_bfrags<D>(gf, gp, p.do_sn, q0, p.N, lane);
+    const LaneOffs<D> L(lane);
+    const bool windowed = p.win_left >= 0 || p.win_right >= 0;
 
     const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
     const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 128 + p.win_right);
@@ -370,17 +437,16 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
 
-    Stage<D, 64> sk, sv;
-    if (t_lo < t_hi) {
-        sk.gload(kp, p.k_sn, t_lo * 64, p.N, tid); sv.gload(vp, p.v_sn, t_lo * 64, p.N, tid);
-        sk.lstore(smem, tid); sv.lstore(smem + TB, tid);
-    }
+    if (t_lo < t_hi) { glds_tile<D, 64>(kp, p.k_sn, t_lo * 64, p.N, smem, tid); glds_tile<D, 64>(vp, p.v_sn, t_lo * 64, p.N, smem + TB, tid); }
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sK = smem + cur * 2 * TB;
         const char* sV = sK + TB;
-        if (t + 1 < t_hi) { sk.gload(kp, p.k_sn, (t + 1) * 64, p.N, tid); sv.gload(vp, p.v_sn, (t + 1) * 64, p.N, tid); }
+        if (t + 1 < t_hi) {
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            glds_tile<D, 64>(kp, p.k_sn, (t + 1) * 64, p.N, dK, tid); glds_tile<D, 64>(vp, p.v_sn, (t + 1) * 64, p.N, dK + TB, tid);
+        }
         const int kv0 = t * 64;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
@@ -389,28 +455,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(const AttnParams p)
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
             for (int st = 0; st < D / 16; ++st) {
-                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, kt * 32, st, lane), qf[st], s, 0, 0, 0);    // S^T[key][q]
-                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, kt * 32, st, lane), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, L, kt * 32, st), qf[st], s, 0, 0, 0);    // S^T[key][q]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, L, kt * 32, st), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
             }
+            if (!(windowed || kv0 + 64 > kv_hi)) {                               // ONE uniform branch, two straight-line bodies
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kv0 + kt * 32 + acc_row(r, hh);
-                bool ok = key < len;
-                if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
-                if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
-                const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - lse2) : 0.f;
-                dp[r] = pr * (dp[r] - dlt);
+                for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + acc_row(r, hh);
+                    bool ok = key < len;
+                    if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
+                    if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
+                    dp[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt) : 0.f;
+                }
             }
             const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
-                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, kt * 32, db * 32, lane), d0, dqt[db], 0, 0, 0);
-                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, kt * 32 + 16, db * 32, lane), d1, dqt[db], 0, 0, 0);
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32, db), d0, dqt[db], 0, 0, 0);
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32 + 16, db), d1, dqt[db], 0, 0, 0);
             }
-        }
-        if (t + 1 < t_hi) {
-            char* dK = smem + (cur ^ 1) * 2 * TB;
-            sk.lstore(dK, tid); sv.lstore(dK + TB, tid);
         }
         __syncthreads();
     }
@@ -422,7 +488,7 @@ void set_lds_attrs() {
     if (done) return;
     (void)hipFuncSetAttribute((const void*)attn_fwd_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
     (void)hipFuncSetAttribute((const void*)attn_bwd_dq_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256);
-    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 32 * 256 + 256));
+    (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * 32 * 256 + 256) + 128 * 256);
     done = true;
 }
 
@@ -489,11 +555,11 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
     dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
     if (D == 128) {
         hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256), stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     } else {
         hipLaunchKernelGGL((attn_delta_kernel<32>), dim3(cdiv(rows * 4, 256)), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<32>), grid, block, 2 * (2 * 32 * 64 + 256), stream, p);
+        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<32>), grid, block, 2 * (2 * 32 * 64 + 256) + 128 * 64, stream, p);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
     }
     SCONF_LAUNCH_OK("sconf_attn_bwd");
