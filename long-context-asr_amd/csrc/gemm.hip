@@ -89,25 +89,33 @@ __device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int ti
 // the per-lane SOURCE address and undone by the same involution on the fragment read (rule "both sides or neither").
 // Rows beyond the matrix are clamped to a valid row (their products are never stored); the K range must be whole
 // 64-deep tiles (checked on the host) because a DMA cannot zero-fill.
+// Per-lane byte offsets of a tile's 4 chunks are loop-invariant over K: computed once per tile (GldsOffs), while the
+// K advance lives in the wave-uniform (SGPR) base pointer, so the staging address math costs no VALU per K-step
+// (global_load_lds saddr + 32-bit voffset form).
+template <bool KS> struct GldsOffs {
+    unsigned off[4];
+    __device__ __forceinline__ void set(long ld, int rows, int row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int c = tid + 256 * i;
+            if (!KS) {
+                const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
+                off[i] = (unsigned)(((long)min(row0 + row, rows - 1) * ld + kc * 8) * 2);
+            } else {
+                const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
+                off[i] = (unsigned)(((long)kr * ld + min(row0 + rc * 8, rows - 8)) * 2);
+            }
+        }
+    }
+};
 template <bool KS>
-__device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, int rows, int row0, int k0, char* s, int tid) {
+__device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, int k0, const GldsOffs<KS>& o, char* s, int tid) {
     typedef const __attribute__((address_space(1))) void* gptr;
     typedef __attribute__((address_space(3))) void* lptr;
+    const char* base = reinterpret_cast<const char*>(P) + (KS ? (long)k0 * ld * 2 : (long)k0 * 2);   // wave-uniform
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = tid + 256 * i;
-        const bf16* src;
-        if (!KS) {
-            const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
-            const int gr = min(row0 + row, rows - 1);
-            src = P + (long)gr * ld + k0 + kc * 8;
-        } else {
-            const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
-            const int gr = min(row0 + rc * 8, rows - 8);
-            src = P + (long)(k0 + kr) * ld + gr;
-        }
-        __builtin_amdgcn_global_load_lds((gptr)src, (lptr)(s + ((tid & ~63) + 256 * i) * 16), 16, 0, 0);
-    }
+    for (int i = 0; i < 4; ++i)
+        __builtin_amdgcn_global_load_lds((gptr)(base + o.off[i]), (lptr)(s + ((tid & ~63) + 256 * i) * 16), 16, 0, 0);
 }
 
 // ---- LDS -> MFMA fragment: 16 rows [rbase, rbase+16) x 32 k of k-step kk --------------------
@@ -195,6 +203,7 @@ __device__ __forceinline__ WorkItem tile_coords(const GemmParams& p, int v, int 
 
 template <bool AKS, bool BKS>
 __device__ __forceinline__ void tile_mma(const char* sA, const char* sB, f32x4 (&acc)[4][4], int wm, int wn, int lane) {
+    // (requesting both k-steps' fragments up front costs 32 more VGPRs and measured 8 % slower on the NN/TN shapes)
 #pragma unroll
     for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[4], bfr[4];
@@ -235,8 +244,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     WorkItem w = tile_coords(p, v, total, ntiles, tiles_m, tiles_n);
 
     if (GLDS) {
-        tile_glds<AKS>(p.A, p.lda, p.M, w.m0, w.kbeg, smem, tid);
-        tile_glds<BKS>(p.B, p.ldb, p.N, w.n0, w.kbeg, smem + TILE_BYTES, tid);
+        GldsOffs<AKS> oa; GldsOffs<BKS> ob;
+        oa.set(p.lda, p.M, w.m0, tid); ob.set(p.ldb, p.N, w.n0, tid);
+        tile_glds<AKS>(p.A, p.lda, w.kbeg, oa, smem, tid);
+        tile_glds<BKS>(p.B, p.ldb, w.kbeg, ob, smem + TILE_BYTES, tid);
         __syncthreads();                                     // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
         int cur = 0;
         while (true) {
@@ -248,11 +259,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 const char* sA = smem + cur * 2 * TILE_BYTES;
                 char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
                 if (kt + 1 < nkt) {                          // next K-tile streams into the other buffer during the MFMAs
-                    tile_glds<AKS>(p.A, p.lda, p.M, w.m0, w.kbeg + (kt + 1) * BK, dA, tid);
-                    tile_glds<BKS>(p.B, p.ldb, p.N, w.n0, w.kbeg + (kt + 1) * BK, dA + TILE_BYTES, tid);
+                    tile_glds<AKS>(p.A, p.lda, w.kbeg + (kt + 1) * BK, oa, dA, tid);
+                    tile_glds<BKS>(p.B, p.ldb, w.kbeg + (kt + 1) * BK, ob, dA + TILE_BYTES, tid);
                 } else if (vn < total) {                     // ... or the NEXT work item's first K-tile
-                    tile_glds<AKS>(p.A, p.lda, p.M, wn_.m0, wn_.kbeg, dA, tid);
-                    tile_glds<BKS>(p.B, p.ldb, p.N, wn_.n0, wn_.kbeg, dA + TILE_BYTES, tid);
+                    oa.set(p.lda, p.M, wn_.m0, tid); ob.set(p.ldb, p.N, wn_.n0, tid);
+                    tile_glds<AKS>(p.A, p.lda, wn_.kbeg, oa, dA, tid);
+                    tile_glds<BKS>(p.B, p.ldb, wn_.kbeg, ob, dA + TILE_BYTES, tid);
                 }
                 tile_mma<AKS, BKS>(sA, sA + TILE_BYTES, acc, wm, wn, lane);
                 if (kt == nkt - 1) {
@@ -294,6 +306,122 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         }
         gemm_epilogue(p, acc, m0, n0, w.split, wm, wn, lane);
     }
+}
+
+// =================================================================================================================
+// Deep-pipelined variant: 256x128x64 block tile, 8 waves (4x2, each 64x64), ONE workgroup per CU, 3-stage LDS ring
+// (3 x 48 KiB), LDS-DMA prefetch distance 2 with a COUNTED s_waitcnt vmcnt(6) and a raw s_barrier per K-step, so two
+// K-steps of loads stay in flight across every barrier (the 2-stage kernel above drains to vmcnt(0) each step).
+// Persistent over (tile, split) work items with the same XCD/L2-patch ordering; the prefetch cursor runs two steps
+// ahead of the compute cursor across item boundaries.  Every step issues exactly 6 LDS-DMA instructions per lane
+// (A: 2 sub-tiles x 2, B: 2) — past the last step the cursor stays clamped and re-loads into the free ring slot —
+// so the wait count is a constant.  Epilogue stores are also VMEM ops: they only make the wait conservative.
+// =================================================================================================================
+constexpr int BM3 = 256, STAGE3 = 3 * TILE_BYTES;      // A: 2 sub-tiles of 128 rows (32 KiB) | B: 16 KiB
+
+template <bool KS> struct Offs512 {                    // 128-row sub-tile, 512 threads -> 2 chunks per thread
+    unsigned off[2];
+    __device__ __forceinline__ void set(long ld, int rows, int row0, int tid) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int c = tid + 512 * i;
+            if (!KS) {
+                const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
+                off[i] = (unsigned)(((long)min(row0 + row, rows - 1) * ld + kc * 8) * 2);
+            } else {
+                const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
+                off[i] = (unsigned)(((long)kr * ld + min(row0 + rc * 8, rows - 8)) * 2);
+            }
+        }
+    }
+};
+template <bool KS>
+__device__ __forceinline__ void sub_glds(const bf16* __restrict__ P, long ld, int k0, const Offs512<KS>& o, char* s, int tid) {
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+    const char* base = reinterpret_cast<const char*>(P) + (KS ? (long)k0 * ld * 2 : (long)k0 * 2);   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        __builtin_amdgcn_global_load_lds((gptr)(base + o.off[i]), (lptr)(s + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
+}
+
+__device__ __forceinline__ WorkItem tile_coords3(const GemmParams& p, int v, int total, int ntiles, int tiles_m, int tiles_n) {
+    const int qx = total >> 3, rx = total & 7, xcd = v & 7;
+    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (v >> 3);
+    const int split = lid / ntiles, t = lid - split * ntiles;
+    constexpr int GM3 = 4;                               // 4 row panels of 256 = the same 1024-row L2 patch as GM=8 x 128
+    const int per_group = GM3 * tiles_n;
+    const int g = t / per_group, r = t - g * per_group;
+    const int first_m = g * GM3, gm = min(GM3, tiles_m - first_m);
+    WorkItem w;
+    w.m0 = (first_m + r % gm) * BM3; w.n0 = (r / gm) * BN;
+    w.split = split;
+    w.kbeg = split * p.k_per_split; w.kend = min(p.K, w.kbeg + p.k_per_split);
+    return w;
+}
+
+template <bool AKS, bool BKS>
+__global__ __launch_bounds__(512, 2) void gemm_kernel3(const GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][A0 16K | A1 16K | B 16K]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;             // wm 0..3
+    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM3 - 1) / BM3;
+    const int ntiles = tiles_m * tiles_n, total = ntiles * p.splits;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    int cv = blockIdx.x;                                 // compute cursor
+    if (cv >= total) return;
+    WorkItem cw = tile_coords3(p, cv, total, ntiles, tiles_m, tiles_n);
+    int ckt = 0, cnkt = (cw.kend - cw.kbeg) / BK;
+
+    int pv = cv; WorkItem pw = cw; int pkt = 0, pnkt = cnkt;   // prefetch cursor (2 steps ahead)
+    Offs512<AKS> oa0, oa1; Offs512<BKS> ob;
+    auto set_offs = [&]() { oa0.set(p.lda, p.M, pw.m0, tid); oa1.set(p.lda, p.M, pw.m0 + 128, tid); ob.set(p.ldb, p.N, pw.n0, tid); };
+    auto issue = [&](int slot) {
+        char* d = smem + slot * STAGE3;
+        const int k0 = pw.kbeg + pkt * BK;
+        sub_glds<AKS>(p.A, p.lda, k0, oa0, d, tid);
+        sub_glds<AKS>(p.A, p.lda, k0, oa1, d + TILE_BYTES, tid);
+        sub_glds<BKS>(p.B, p.ldb, k0, ob, d + 2 * TILE_BYTES, tid);
+    };
+    auto advance = [&]() {
+        if (pkt + 1 < pnkt) { ++pkt; return; }
+        const int vn = pv + gridDim.x;
+        if (vn < total) { pv = vn; pw = tile_coords3(p, pv, total, ntiles, tiles_m, tiles_n); pkt = 0; pnkt = (pw.kend - pw.kbeg) / BK; set_offs(); }
+        // else: stay clamped on the last step (harmless re-load into the free ring slot keeps the wait count constant)
+    };
+    set_offs();
+    issue(0); advance();
+    issue(1); advance();
+
+    int slot = 0;
+    while (true) {
+        // tile for this step has landed for THIS wave when at most the 6 youngest VMEM ops (next step's DMA) are pending;
+        // the barrier then makes every wave's share visible and frees the slot that step+2 is about to overwrite.
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+        int pslot = slot + 2; if (pslot >= 3) pslot -= 3;
+        issue(pslot); advance();
+        const char* sA = smem + slot * STAGE3 + (wm >> 1) * TILE_BYTES;
+        const char* sB = smem + slot * STAGE3 + 2 * TILE_BYTES;
+        tile_mma<AKS, BKS>(sA, sB, acc, wm & 1, wn, lane);
+        if (++slot == 3) slot = 0;
+        if (++ckt == cnkt) {
+            gemm_epilogue(p, acc, cw.m0 + (wm >> 1) * 128, cw.n0, cw.split, wm & 1, wn, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int vn = cv + gridDim.x;
+            if (vn >= total) break;
+            cv = vn; cw = tile_coords3(p, cv, total, ntiles, tiles_m, tiles_n); ckt = 0; cnkt = (cw.kend - cw.kbeg) / BK;
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, long n, int accumulate) {
@@ -363,9 +491,30 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
         no_glds = getenv("SCONF_GEMM_NO_GLDS") != nullptr;      // A/B switch for benchmarking the two staging paths
         attr_set = true;
     }
-    // LDS-DMA staging needs whole 64-deep K tiles (no zero fill) and at least one full 8-row chunk to clamp to.
-    const bool glds = !no_glds && K % BK == 0 && M >= 8 && N >= 8;
-    if (glds) {
+    // LDS-DMA staging needs whole 64-deep K tiles (no zero fill), at least one full 8-row chunk to clamp to, and
+    // operands addressable with 32-bit byte offsets from a uniform base.
+    const bool glds = !no_glds && K % BK == 0 && M >= 8 && N >= 8 &&
+                      (long)(aks ? K : M) * lda * 2 < (1L << 32) && (long)(bks ? K : N) * ldb * 2 < (1L << 32);
+    // The deep-pipelined 256x128 kernel measured no better than the 2-stage 128x128 one on this workload (it wins
+    // ~9 % on long-K NT shapes, loses 10-20 % on the NN/TN shapes), i.e. the 2-stage kernel is not latency-bound:
+    // it stays opt-in for experiments.
+    static bool use_v3 = getenv("SCONF_GEMM_V3") != nullptr;
+    if (glds && use_v3 && M >= 256) {
+        static bool a3 = false;
+        if (!a3) {
+            (void)hipFuncSetAttribute((const void*)gemm_kernel3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+            (void)hipFuncSetAttribute((const void*)gemm_kernel3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
+            a3 = true;
+        }
+        static int cus = 0;
+        if (!cus) { int n = sconf_num_cus(); cus = n > 0 ? n : 256; }
+        const int nt3 = cdiv(M, BM3) * cdiv(N, BN);
+        dim3 g3(std::min(nt3 * splits, cus)), b3(512);
+        if (layout == 0)      hipLaunchKernelGGL((gemm_kernel3<false, false>), g3, b3, 3 * STAGE3, stream, p);
+        else if (layout == 1) hipLaunchKernelGGL((gemm_kernel3<false, true>), g3, b3, 3 * STAGE3, stream, p);
+        else                  hipLaunchKernelGGL((gemm_kernel3<true, true>), g3, b3, 3 * STAGE3, stream, p);
+    } else if (glds) {
         static int slots = 0;
         if (!slots) { int n = sconf_num_cus(); slots = 2 * (n > 0 ? n : 256); }
         grid.x = std::min(ntiles * splits, slots);                // persistent: <= 2 resident workgroups per CU
