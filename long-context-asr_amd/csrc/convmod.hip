@@ -17,19 +17,56 @@ namespace {
 
 constexpr int CV = 4;                               // channels per thread
 
+// Workgroup geometry of the sliding-window kernels: 256 threads = CPB channel groups x SPB time slabs, blockIdx.y picks
+// the block of CPB channel groups.  Keeping many slabs of the SAME channels in one workgroup lets per-channel sums be
+// reduced through LDS and flushed as ONE well-shaped atomic per channel per workgroup (64 lanes -> 64 consecutive
+// floats): per-thread atomics on a few thousand addresses, 64 lanes in 64 different lines, ran at ~0.08 TB/s and
+// dominated these kernels.
+struct SlabGeo {
+    int cg, sl, cpb, spb;
+    bool active;
+    __device__ __forceinline__ SlabGeo(int CG) {
+        cpb = min(64, CG); spb = 256 / cpb;
+        const int cgl = threadIdx.x % cpb;
+        sl = threadIdx.x / cpb;
+        cg = blockIdx.y * cpb + cgl;
+        active = cg < CG && sl < spb;
+    }
+};
+// sum v[CV] (this thread's channels) over the workgroup's slabs; thread (sl==0) ends up owning nothing special: instead
+// lane i of the first cpb*CV threads adds channel (blockIdx.y*cpb*CV + i).  `sh` needs 1024 floats.
+template <typename AT>
+__device__ __forceinline__ void slab_reduce_add(const float (&v)[CV], const SlabGeo& g, float* sh, AT* out, int d) {
+    __syncthreads();
+    if (threadIdx.x < g.cpb * g.spb) {
+#pragma unroll
+        for (int e = 0; e < CV; ++e) sh[g.sl * (g.cpb * CV) + (threadIdx.x % g.cpb) * CV + e] = g.active ? v[e] : 0.f;
+    }
+    __syncthreads();
+    const int nch = g.cpb * CV;
+    if ((int)threadIdx.x < nch) {
+        const int c = blockIdx.y * nch + threadIdx.x;
+        if (c < d) {
+            float a = 0.f;
+            for (int s_ = 0; s_ < g.spb; ++s_) a += sh[s_ * nch + threadIdx.x];
+            atomicAdd(out + c, (AT)a);
+        }
+    }
+}
+
 template <int K>
 __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16* __restrict__ g, const int* __restrict__ len,
                                                              const float* __restrict__ w, const float* __restrict__ bias,
                                                              bf16* __restrict__ h, double* __restrict__ stats,
                                                              int B, int N, int d, int TN) {
     constexpr int P = (K - 1) / 2;
+    __shared__ float red[1024];
     const int CG = d / CV, spb = (N + TN - 1) / TN;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * spb * CG) return;
-    const int cg = (int)(idx % CG);
-    const long slab = idx / CG;
-    const int b = (int)(slab / spb), n0 = (int)(slab % spb) * TN;
-    const int c0 = cg * CV;
+    const SlabGeo geo(CG);
+    const long slab = (long)blockIdx.x * geo.spb + geo.sl;
+    const bool live = geo.active && slab < (long)B * spb;
+    const int b = live ? (int)(slab / spb) : 0, n0 = live ? (int)(slab % spb) * TN : 0;
+    const int c0 = live ? geo.cg * CV : 0;
     const int L = len ? len[b] : N;
     float wk[K][CV], win[K][CV], bs[CV];
 #pragma unroll
@@ -40,21 +77,26 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16* __restr
     }
     float s1[CV] = {0.f, 0.f, 0.f, 0.f}, s2[CV] = {0.f, 0.f, 0.f, 0.f};
     const bf16* gb = g + (long)b * N * 2 * d;
-    const int nend = min(N, n0 + TN);
+    const int nend = live ? min(N, n0 + TN) : n0 - 2 * P;        // dead threads run an empty loop, then join the reductions
+    const bf16x4 z4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    auto fetch = [&](int t, bf16x4& va, bf16x4& ga) {
+        va = z4; ga = z4;
+        if (t >= 0 && t < N && t < L) {
+            va = *reinterpret_cast<const bf16x4*>(gb + (long)t * 2 * d + c0);
+            ga = *reinterpret_cast<const bf16x4*>(gb + (long)t * 2 * d + d + c0);
+        }
+    };
+    bf16x4 cva, cga;
+    fetch(n0 - P, cva, cga);
     for (int t = n0 - P; t < nend + P; ++t) {
+        bf16x4 nva, nga;
+        fetch(t + 1 < nend + P ? t + 1 : -1000000, nva, nga);          // next step's loads fly during this step
 #pragma unroll
         for (int j = 0; j < K - 1; ++j)
 #pragma unroll
             for (int e = 0; e < CV; ++e) win[j][e] = win[j + 1][e];
-        if (t >= 0 && t < N && t < L) {
-            float va[CV], ga[CV];
-            load4(gb + (long)t * 2 * d + c0, va); load4(gb + (long)t * 2 * d + d + c0, ga);
 #pragma unroll
-            for (int e = 0; e < CV; ++e) win[K - 1][e] = va[e] * sigmoidf_(ga[e]);
-        } else {
-#pragma unroll
-            for (int e = 0; e < CV; ++e) win[K - 1][e] = 0.f;
-        }
+        for (int e = 0; e < CV; ++e) win[K - 1][e] = (float)cva[e] * sigmoidf_((float)cga[e]);   // zeros outside [0, min(N,L))
         const int n = t - P;                         // window now holds a[n-P .. n+P]
         if (n >= n0 && n < nend) {
             float o[CV];
@@ -70,10 +112,11 @@ __global__ __launch_bounds__(256) void glu_dwconv_fwd_kernel(const bf16* __restr
             }
             store4(h + ((long)b * N + n) * d + c0, o);
         }
+        cva = nva; cga = nga;
     }
     if (stats) {
-#pragma unroll
-        for (int e = 0; e < CV; ++e) { atomicAdd(stats + c0 + e, (double)s1[e]); atomicAdd(stats + d + c0 + e, (double)s2[e]); }
+        slab_reduce_add<double>(s1, geo, red, stats, d);
+        slab_reduce_add<double>(s2, geo, red, stats + d, d);
     }
 }
 
@@ -125,28 +168,39 @@ __global__ void affine_silu_fwd_kernel(const bf16* __restrict__ h, const float* 
 __global__ __launch_bounds__(256) void brn_bwd_reduce_kernel(const bf16* __restrict__ dy, const bf16* __restrict__ h,
                                                              const float* __restrict__ coef, double* __restrict__ red,
                                                              long M, int d, int rows_per_thread) {
+    __shared__ float redb[1024];
     const int CG = d / CV;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const SlabGeo geo(CG);
     const long nslab = (M + rows_per_thread - 1) / rows_per_thread;
-    if (idx >= nslab * CG) return;
-    const int c0 = (int)(idx % CG) * CV;
-    const long r0 = (idx / CG) * rows_per_thread, r1 = min(M, r0 + rows_per_thread);
+    const long slab = (long)blockIdx.x * geo.spb + geo.sl;
+    const bool live = geo.active && slab < nslab;
+    const int c0 = live ? geo.cg * CV : 0;
+    const long r0 = live ? slab * rows_per_thread : 0, r1 = live ? min(M, r0 + rows_per_thread) : 0;
     float mean[CV], is[CV], A[CV], Bc[CV];
     load4(coef + c0, mean); load4(coef + d + c0, is); load4(coef + 4 * d + c0, A); load4(coef + 5 * d + c0, Bc);
 #pragma unroll
     for (int e = 0; e < CV; ++e) is[e] = 1.f / is[e];
     float s1[CV] = {0.f, 0.f, 0.f, 0.f}, s2[CV] = {0.f, 0.f, 0.f, 0.f};
-    for (long r = r0; r < r1; ++r) {
-        float g[CV], x[CV];
-        load4(dy + r * d + c0, g); load4(h + r * d + c0, x);
+    for (long r = r0; r < r1; r += 4) {                      // 4 rows of loads in flight per thread
+        float g[4][CV], x[4][CV];
 #pragma unroll
-        for (int e = 0; e < CV; ++e) {
-            const float dz = g[e] * dsiluf_(x[e] * A[e] + Bc[e]);
-            s1[e] += dz; s2[e] += dz * (x[e] - mean[e]) * is[e];
+        for (int u = 0; u < 4; ++u) {
+            if (r + u < r1) { load4(dy + (r + u) * d + c0, g[u]); load4(h + (r + u) * d + c0, x[u]); }
+            else {
+#pragma unroll
+                for (int e = 0; e < CV; ++e) { g[u][e] = 0.f; x[u][e] = mean[e]; }
+            }
         }
-    }
 #pragma unroll
-    for (int e = 0; e < CV; ++e) { atomicAdd(red + c0 + e, (double)s1[e]); atomicAdd(red + d + c0 + e, (double)s2[e]); }
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int e = 0; e < CV; ++e) {
+                const float dz = g[u][e] * dsiluf_(x[u][e] * A[e] + Bc[e]);
+                s1[e] += dz; s2[e] += dz * (x[u][e] - mean[e]) * is[e];
+            }
+    }
+    slab_reduce_add<double>(s1, geo, redb, red, d);
+    slab_reduce_add<double>(s2, geo, redb, red + d, d);
 }
 
 // bcoef rows: 0 k0, 1 k1, 2 k2  with  dh = k0*dz - k1 - xhat0*k2 ; accumulates d(weight), d(bias) of BatchRenorm
@@ -174,16 +228,16 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
                                                              const bf16* __restrict__ g, const int* __restrict__ len,
                                                              const float* __restrict__ w, const float* __restrict__ coef,
                                                              const float* __restrict__ bcoef, bf16* __restrict__ dg,
-                                                             float* __restrict__ dw, float* __restrict__ dbias,
+                                                             float* __restrict__ dwt, float* __restrict__ dbias,
                                                              int B, int N, int d, int TN) {
     constexpr int P = (K - 1) / 2;
+    __shared__ float redw[1024];
     const int CG = d / CV, spb = (N + TN - 1) / TN;
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long)B * spb * CG) return;
-    const int cg = (int)(idx % CG);
-    const long slab = idx / CG;
-    const int b = (int)(slab / spb), n0 = (int)(slab % spb) * TN;
-    const int c0 = cg * CV;
+    const SlabGeo geo(CG);
+    const long slab = (long)blockIdx.x * geo.spb + geo.sl;
+    const bool live = geo.active && slab < (long)B * spb;
+    const int b = live ? (int)(slab / spb) : 0, n0 = live ? (int)(slab % spb) * TN : 0;
+    const int c0 = live ? geo.cg * CV : 0;
     const int L = len ? len[b] : N;
     float wk[K][CV], dhw[K][CV], aw[K][CV], gw[K][CV], gb[CV];
     float mean[CV], is[CV], A[CV], Bc[CV], k0[CV], k1[CV], k2[CV];
@@ -196,31 +250,45 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
         for (int j = 0; j < K; ++j) { wk[j][e] = w[(c0 + e) * K + j]; dhw[j][e] = 0.f; aw[j][e] = 0.f; gw[j][e] = 0.f; }
     }
     const bf16* gbp = g + (long)b * N * 2 * d;
-    const int nend = min(N, n0 + TN);
+    const int nend = live ? min(N, n0 + TN) : n0 - 2 * P;        // dead threads: empty loop, then join the reductions
     // The dw-conv weight gradient  dW[j] = sum_n dh[n] * a[n + j - P]  is accumulated for window CENTRES in
     // [n0, nend) only, so slabs partition the sum exactly.
+    // Software pipeline: the raw loads of step t+1 (leading edge dy/h/g and the centre's g) are issued before step t is
+    // processed — the loop is a serial chain per thread and was latency-bound, not bandwidth-bound.
+    struct Raw { bf16x4 gy, hx, va, ga, cva, cga; };
+    const bf16x4 z4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+    auto fetch = [&](int t) {
+        Raw r; r.gy = z4; r.hx = z4; r.va = z4; r.ga = z4; r.cva = z4; r.cga = z4;
+        if (t >= 0 && t < N) {
+            const long row = (long)b * N + t;
+            r.gy = *reinterpret_cast<const bf16x4*>(dy + row * d + c0);
+            r.hx = *reinterpret_cast<const bf16x4*>(h + row * d + c0);
+            if (t < L) {
+                r.va = *reinterpret_cast<const bf16x4*>(gbp + (long)t * 2 * d + c0);
+                r.ga = *reinterpret_cast<const bf16x4*>(gbp + (long)t * 2 * d + d + c0);
+            }
+        }
+        const int n = t - P;
+        if (n >= n0 && n < nend && n < L) {
+            r.cva = *reinterpret_cast<const bf16x4*>(gbp + (long)n * 2 * d + c0);
+            r.cga = *reinterpret_cast<const bf16x4*>(gbp + (long)n * 2 * d + d + c0);
+        }
+        return r;
+    };
+    Raw cur = fetch(n0 - P);
     for (int t = n0 - P; t < nend + P; ++t) {
+        const Raw nxt = fetch(t + 1 < nend + P ? t + 1 : -1000000);
 #pragma unroll
         for (int j = 0; j < K - 1; ++j)
 #pragma unroll
             for (int e = 0; e < CV; ++e) { dhw[j][e] = dhw[j + 1][e]; aw[j][e] = aw[j + 1][e]; }
         if (t >= 0 && t < N) {
-            float gy[CV], hx[CV];
-            const long row = (long)b * N + t;
-            load4(dy + row * d + c0, gy); load4(h + row * d + c0, hx);
 #pragma unroll
             for (int e = 0; e < CV; ++e) {
-                const float dz = gy[e] * dsiluf_(hx[e] * A[e] + Bc[e]);
-                dhw[K - 1][e] = k0[e] * dz - k1[e] - (hx[e] - mean[e]) * is[e] * k2[e];
-            }
-            if (t < L) {
-                float va[CV], ga[CV];
-                load4(gbp + (long)t * 2 * d + c0, va); load4(gbp + (long)t * 2 * d + d + c0, ga);
-#pragma unroll
-                for (int e = 0; e < CV; ++e) aw[K - 1][e] = va[e] * sigmoidf_(ga[e]);
-            } else {
-#pragma unroll
-                for (int e = 0; e < CV; ++e) aw[K - 1][e] = 0.f;
+                const float hx = (float)cur.hx[e];
+                const float dz = (float)cur.gy[e] * dsiluf_(hx * A[e] + Bc[e]);
+                dhw[K - 1][e] = k0[e] * dz - k1[e] - (hx - mean[e]) * is[e] * k2[e];
+                aw[K - 1][e] = (t < L) ? (float)cur.va[e] * sigmoidf_((float)cur.ga[e]) : 0.f;
             }
         } else {
 #pragma unroll
@@ -228,38 +296,28 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
         }
         const int n = t - P;                         // windows hold dh[n-P..n+P], a[n-P..n+P]
         if (n >= n0 && n < nend) {
-            float da[CV];
+            float dv[CV], dgt[CV];
 #pragma unroll
             for (int e = 0; e < CV; ++e) {
                 float acc = 0.f;
                 const float dhc = dhw[P][e];
 #pragma unroll
                 for (int j = 0; j < K; ++j) { acc += wk[j][e] * dhw[K - 1 - j][e]; gw[j][e] += dhc * aw[j][e]; }
-                da[e] = acc; gb[e] += dhc;
-            }
-            float dv[CV], dgt[CV];
-            if (n < L) {
-                float va[CV], ga[CV];
-                load4(gbp + (long)n * 2 * d + c0, va); load4(gbp + (long)n * 2 * d + d + c0, ga);
-#pragma unroll
-                for (int e = 0; e < CV; ++e) {
-                    const float sg = sigmoidf_(ga[e]);
-                    dv[e] = da[e] * sg; dgt[e] = da[e] * va[e] * sg * (1.f - sg);
-                }
-            } else {
-#pragma unroll
-                for (int e = 0; e < CV; ++e) { dv[e] = 0.f; dgt[e] = 0.f; }
+                gb[e] += dhc;
+                if (n < L) {
+                    const float sg = sigmoidf_((float)cur.cga[e]);
+                    dv[e] = acc * sg; dgt[e] = acc * (float)cur.cva[e] * sg * (1.f - sg);
+                } else { dv[e] = 0.f; dgt[e] = 0.f; }
             }
             bf16* o = dg + ((long)b * N + n) * 2 * d;
             store4(o + c0, dv); store4(o + d + c0, dgt);
         }
+        cur = nxt;
     }
+    // gradients of the K taps are accumulated TRANSPOSED (dwt[j][c]) so a wave's atomics hit consecutive floats
+    slab_reduce_add<float>(gb, geo, redw, dbias, d);
 #pragma unroll
-    for (int e = 0; e < CV; ++e) {
-        atomicAdd(dbias + c0 + e, gb[e]);
-#pragma unroll
-        for (int j = 0; j < K; ++j) atomicAdd(dw + (c0 + e) * K + j, gw[j][e]);
-    }
+    for (int j = 0; j < K; ++j) slab_reduce_add<float>(gw[j], geo, redw, dwt + (long)j * d, d);
 }
 
 int pick_tn(long B, long N, long CG) {
@@ -278,8 +336,8 @@ SCONF_API int sconf_glu_dwconv_fwd(const void* g, const int32_t* lengths, const 
     SCONF_REQUIRE(d % CV == 0, "sconf_glu_dwconv_fwd: d must be a multiple of 4");
     if (B * N == 0) return 0;
     const int TN = pick_tn(B, N, d / CV);
-    const long threads = B * cdiv(N, TN) * (d / CV);
-    dim3 grid(cdiv(threads, 256)), block(256);
+    const int cpb = (int)std::min<long>(64, d / CV), spbk = 256 / cpb;
+    dim3 grid(cdiv(B * cdiv(N, TN), spbk), cdiv(d / CV, cpb)), block(256);
 #define L(KK) hipLaunchKernelGGL((glu_dwconv_fwd_kernel<KK>), grid, block, 0, stream, (const bf16*)g, lengths, w, bias, (bf16*)h, stats, (int)B, (int)N, (int)d, TN)
     switch (ksize) { case 3: L(3); break; case 5: L(5); break; case 7: L(7); break; case 9: L(9); break;
         default: return sconf_set_error("sconf_glu_dwconv_fwd: unsupported kernel size %ld (3,5,7,9)", (long)ksize); }
@@ -312,7 +370,8 @@ SCONF_API int sconf_affine_silu_fwd(const void* h, const float* coef, void* y, i
 
 // Backward of [GLU -> mask -> dwconv -> BatchRenorm -> SiLU].  dy: grad wrt the SiLU output (B,N,d) bf16.
 // red: f64 [2][d] scratch PRE-ZEROED; bcoef: f32 [3][d] scratch.  Writes dg (B,N,2d) bf16; ACCUMULATES (+=)
-// d(dw weight) [d][k], d(dw bias) [d], d(brn weight) [d], d(brn bias) [d].
+// d(dw weight) TRANSPOSED as [k][d] (the caller transposes the tiny tensor back), d(dw bias) [d], d(brn weight) [d],
+// d(brn bias) [d].
 SCONF_API int sconf_convmod_bwd(const void* dy, const void* h, const void* g, const int32_t* lengths, const float* w,
                                 const float* brn_weight, const float* coef, double* red, float* bcoef, void* dg,
                                 float* dw, float* dbias, float* dbrn_weight, float* dbrn_bias,
@@ -323,13 +382,13 @@ SCONF_API int sconf_convmod_bwd(const void* dy, const void* h, const void* g, co
     const int CG = (int)(d / CV);
     int rpt = 64;
     while (rpt > 8 && cdiv(M, rpt) * CG < 131072) rpt >>= 1;
-    hipLaunchKernelGGL(brn_bwd_reduce_kernel, dim3(cdiv(cdiv(M, rpt) * (long)CG, 256)), dim3(256), 0, stream,
+    const int cpb = std::min(64, CG), spbk = 256 / cpb;
+    hipLaunchKernelGGL(brn_bwd_reduce_kernel, dim3(cdiv(cdiv(M, rpt), spbk), cdiv(CG, cpb)), dim3(256), 0, stream,
                        (const bf16*)dy, (const bf16*)h, coef, red, M, (int)d, rpt);
     hipLaunchKernelGGL(brn_bwd_finalize_kernel, dim3(cdiv(d, 256)), dim3(256), 0, stream, red, (double)M, coef, brn_weight,
                        bcoef, dbrn_weight, dbrn_bias, (int)d, training, eps);
     const int TN = pick_tn(B, N, CG);
-    const long threads = B * cdiv(N, TN) * CG;
-    dim3 grid(cdiv(threads, 256)), block(256);
+    dim3 grid(cdiv(B * cdiv(N, TN), spbk), cdiv(CG, cpb)), block(256);
 #define L(KK) hipLaunchKernelGGL((dwconv_glu_bwd_kernel<KK>), grid, block, 0, stream, (const bf16*)dy, (const bf16*)h, (const bf16*)g, lengths, w, coef, bcoef, (bf16*)dg, dw, dbias, (int)B, (int)N, (int)d, TN)
     switch (ksize) { case 3: L(3); break; case 5: L(5); break; case 7: L(7); break; case 9: L(9); break;
         default: return sconf_set_error("sconf_convmod_bwd: unsupported kernel size %ld (3,5,7,9)", (long)ksize); }

@@ -13,9 +13,10 @@
 
 namespace {
 
-constexpr int MAXIT = 8;                    // d <= 8 * 256 = 2048
+constexpr int MAXD = 2048;                   // d <= 8 * 256; kernels are instantiated for NIT = ceil(d/256) in {1,2,3,4,8}
+// so a d=768 row costs 3 (not 8) register iterations: occupancy, not bandwidth, was the limit at small d.
 
-template <typename TI, typename TO, int MODE>
+template <typename TI, typename TO, int MODE, int MAXIT>
 __global__ __launch_bounds__(256) void norm_fwd_kernel(const TI* __restrict__ x, const float* __restrict__ w,
                                                        const float* __restrict__ b, TO* __restrict__ y,
                                                        float* __restrict__ stat_mean, float* __restrict__ stat_rstd,
@@ -70,7 +71,7 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const TI* __restrict__ x,
     }
 }
 
-template <typename TI, typename TG, typename TO, int MODE>
+template <typename TI, typename TG, typename TO, int MODE, int MAXIT>
 __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy, const TI* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ stat_mean,
                                                        const float* __restrict__ stat_rstd, const float* __restrict__ dres,
@@ -156,11 +157,11 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
     }
 }
 
-template <int MODE>
+template <int MODE, int NIT>
 int launch_fwd(const void* x, int xdt, const float* w, const float* b, void* y, int ydt, float* mean, float* rstd,
                int M, int d, float eps, hipStream_t st) {
     dim3 grid(cdiv(M, 4)), block(256);
-#define L(TI, TO) hipLaunchKernelGGL((norm_fwd_kernel<TI, TO, MODE>), grid, block, 0, st, (const TI*)x, w, b, (TO*)y, mean, rstd, M, d, eps)
+#define L(TI, TO) hipLaunchKernelGGL((norm_fwd_kernel<TI, TO, MODE, NIT>), grid, block, 0, st, (const TI*)x, w, b, (TO*)y, mean, rstd, M, d, eps)
     if (xdt == SCONF_F32 && ydt == SCONF_F32) L(float, float);
     else if (xdt == SCONF_F32 && ydt == SCONF_BF16) L(float, bf16);
     else if (xdt == SCONF_BF16 && ydt == SCONF_BF16) L(bf16, bf16);
@@ -169,11 +170,11 @@ int launch_fwd(const void* x, int xdt, const float* w, const float* b, void* y, 
     return 0;
 }
 
-template <int MODE>
+template <int MODE, int NIT>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
                const float* dres, void* dx, int odt, float* dw, float* db, int M, int d, float eps, hipStream_t st) {
     dim3 grid(min(cdiv(M, 4), 512)), block(256);
-#define L(TI, TG, TO) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, M, d, eps)
+#define L(TI, TG, TO) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, M, d, eps)
     if (xdt == SCONF_F32) {
         if (gdt == SCONF_F32) { if (odt == SCONF_F32) L(float, float, float); else L(float, float, bf16); }
         else                  { if (odt == SCONF_F32) L(float, bf16, float);  else L(float, bf16, bf16); }
@@ -185,6 +186,10 @@ int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, 
     return 0;
 }
 
+#define NIT_DISPATCH(FN, MODE_, ...) do { const int nit_ = (int)((d + 255) / 256); \
+    if (nit_ <= 1) FN<MODE_, 1>(__VA_ARGS__); else if (nit_ <= 2) FN<MODE_, 2>(__VA_ARGS__); else if (nit_ <= 3) FN<MODE_, 3>(__VA_ARGS__); \
+    else if (nit_ <= 4) FN<MODE_, 4>(__VA_ARGS__); else FN<MODE_, 8>(__VA_ARGS__); } while (0)
+
 }  // namespace
 
 // Replaces torch.nn.LayerNorm / apex FusedLayerNorm / RMSNorm forward (sconformer_xl.py:14-17, normalisation.py:34-47).
@@ -192,12 +197,12 @@ SCONF_API int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* 
                              void* y, int y_dtype, float* mean, float* rstd, int64_t M, int64_t d, float eps,
                              hipStream_t stream) {
     SCONF_REQUIRE(mode >= 0 && mode <= 2, "sconf_norm_fwd: bad mode %d", mode);
-    SCONF_REQUIRE(d % 4 == 0 && d <= MAXIT * 256 && d > 0, "sconf_norm_fwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
+    SCONF_REQUIRE(d % 4 == 0 && d <= MAXD && d > 0, "sconf_norm_fwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm_fwd: too many rows");
     if (M == 0) return 0;
-    if (mode == 0) launch_fwd<0>(x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
-    else if (mode == 1) launch_fwd<1>(x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
-    else launch_fwd<2>(x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
+    if (mode == 0) NIT_DISPATCH(launch_fwd, 0, x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
+    else if (mode == 1) NIT_DISPATCH(launch_fwd, 1, x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
+    else NIT_DISPATCH(launch_fwd, 2, x, x_dtype, weight, bias, y, y_dtype, mean, rstd, (int)M, (int)d, eps, stream);
     SCONF_LAUNCH_OK("sconf_norm_fwd");
     return 0;
 }
@@ -207,12 +212,12 @@ SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void*
                              const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype,
                              float* dweight, float* dbias, int64_t M, int64_t d, float eps, hipStream_t stream) {
     SCONF_REQUIRE(mode >= 0 && mode <= 2, "sconf_norm_bwd: bad mode %d", mode);
-    SCONF_REQUIRE(d % 4 == 0 && d <= MAXIT * 256 && d > 0, "sconf_norm_bwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
+    SCONF_REQUIRE(d % 4 == 0 && d <= MAXD && d > 0, "sconf_norm_bwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm_bwd: too many rows");
     if (M == 0) return 0;
-    if (mode == 0) launch_bwd<0>(dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
-    else if (mode == 1) launch_bwd<1>(dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
-    else launch_bwd<2>(dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
+    if (mode == 0) NIT_DISPATCH(launch_bwd, 0, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
+    else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
+    else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
     SCONF_LAUNCH_OK("sconf_norm_bwd");
     return 0;
 }

@@ -287,8 +287,10 @@ def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B: int, N: int, training
     dg = torch.empty(B * N, 2 * d, dtype=torch.bfloat16, device=dy.device)
     red = torch.zeros(2, d, dtype=torch.float64, device=dy.device)
     bcoef = torch.empty(3, d, dtype=torch.float32, device=dy.device)
+    dwt = torch.zeros(ks, d, dtype=torch.float32, device=dy.device)       # kernel accumulates the tap gradients as [k][d]
     _lib.call('sconf_convmod_bwd', _p(dy), _p(h), _p(g), _p(lengths), _p(w), _p(brn_weight), _p(coef), _p(red), _p(bcoef), _p(dg),
-              _p(dw), _p(dbias), _p(dbrn_weight), _p(dbrn_bias), B, N, d, ks, int(training), float(eps), _stream())
+              _p(dwt), _p(dbias), _p(dbrn_weight), _p(dbrn_bias), B, N, d, ks, int(training), float(eps), _stream())
+    dw.add_(dwt.t())
     return dg
 
 
