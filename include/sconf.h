@@ -103,6 +103,13 @@ int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void* pre_in, v
                          int64_t B, int64_t Ti, int64_t Fi, int64_t C, sconf_stream_t stream);
 int sconf_sub_conv0_bwd(const void* dpre0, const void* x, int x_dtype, float* dw, float* dbias, int64_t B, int64_t F,
                         int64_t T, int64_t C, sconf_stream_t stream);
+/* Fused stage 0->1 (conv0 + SiLU + first depthwise conv) without the (B,T/2,F/2,C) intermediate, and its parameter-gradient
+ * backward (dw0,db0,dwd,dbd ACCUMULATED) from dd1 (B,T4,F4,C) bf16.  subsampling.py:299-318. */
+int sconf_sub_stage01_fwd(const void* x, int x_dtype, const float* w0, const float* b0, const float* wd, const float* bd,
+                          void* d1, int64_t B, int64_t F, int64_t T, int64_t C, sconf_stream_t stream);
+int sconf_sub_stage01_bwd(const void* dd1, const void* x, int x_dtype, const float* w0, const float* b0, const float* wd,
+                          float* dw0, float* db0, float* dwd, float* dbd, int64_t B, int64_t F, int64_t T, int64_t C,
+                          sconf_stream_t stream);
 int sconf_sub_silu_transpose(int bwd, const void* pre, const void* ds, void* out, int64_t rows, int64_t F8, int64_t C,
                              sconf_stream_t stream);
 

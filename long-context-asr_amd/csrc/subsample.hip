@@ -245,6 +245,236 @@ __global__ __launch_bounds__(256) void silu_transpose_kernel(const bf16* __restr
     }
 }
 
+// =================================================================================================================
+// Fused stage 0 -> 1: conv0 (1->C, 3x3 s2) + SiLU + depthwise 3x3 s2, WITHOUT materialising the (B,T/2,F/2,C) tensor
+// (2.7 GB bf16 per 16 x 16384-frame batch; 2.7 GB more for its gradient).  conv0 is 9 MACs per output on a single-channel
+// input, so it is recomputed from a mel patch staged in LDS wherever it is needed (forward, dw-conv weight gradient,
+// conv0 weight gradient): the three kernels below read the mel rows + the small stage-1 tensors only.
+// Geometry: a workgroup walks time rows; per row it stages NT mel time-columns x F bins in LDS; a thread owns 4 channels
+// (its 2 x 9 taps + biases in registers) and loops over the row's frequency positions.
+// =================================================================================================================
+constexpr int FC = 4;                                    // channels per thread in the fused kernels
+
+template <typename TX, int NT>
+__device__ __forceinline__ void stage_mel(const TX* __restrict__ xb, float* xs, int F, int T, int t_base) {
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < NT * F; idx += 256) {
+        const int f = idx / NT, tt = idx - f * NT, t = t_base + tt;
+        xs[tt * F + f] = (t >= 0 && t < T) ? ld_f(xb + (long)f * T + t) : 0.f;
+    }
+    __syncthreads();
+}
+// pre0 at conv0 position (t2, f2) for 4 channels, from the LDS mel patch whose row 0 is time t_base
+__device__ __forceinline__ void conv0_at(const float* xs, int F, int tt0, int f2, const float (&w0)[9][FC], const float (&b0)[FC],
+                                         float (&pre)[FC], float (&xin)[9]) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            const int f = 2 * f2 + b - 1;
+            xin[a * 3 + b] = (f >= 0 && f < F) ? xs[(tt0 + a) * F + f] : 0.f;
+        }
+#pragma unroll
+    for (int e = 0; e < FC; ++e) {
+        float acc = b0[e];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) acc += w0[k][e] * xin[k];
+        pre[e] = acc;
+    }
+}
+
+struct FGeo {                                            // thread -> (channel group, position lane)
+    int cg, plane, c0, PL;
+    bool active;
+    __device__ __forceinline__ FGeo(int C) {
+        const int cgs = C / FC;
+        PL = max(1, 256 / cgs);
+        cg = threadIdx.x % cgs; plane = threadIdx.x / cgs; c0 = cg * FC;
+        active = plane < PL;
+    }
+};
+
+// d1[t4][f4][c] = bd[c] + sum_{i,j} wd[c][i][j] * SiLU(pre0[2t4+i-1][2f4+j-1][c])      (zero padding of the SiLU output)
+template <typename TX>
+__global__ __launch_bounds__(256) void stage01_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+                                                          const float* __restrict__ wdg, const float* __restrict__ bdg, bf16* __restrict__ d1,
+                                                          int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
+    extern __shared__ float xs[];                        // [7][F]
+    const FGeo g(C);
+    const int b = blockIdx.y;
+    float w0[9][FC], b0[FC], wd[9][FC], bd[FC];
+#pragma unroll
+    for (int e = 0; e < FC; ++e) {
+        const int c = g.active ? g.c0 + e : 0;
+        b0[e] = b0g[c]; bd[e] = bdg[c];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; wd[k][e] = wdg[c * 9 + k]; }
+    }
+    const TX* xb = x + (long)b * F * T;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(T4, r0 + rows_per_block);
+    for (int t4 = r0; t4 < r1; ++t4) {
+        stage_mel<TX, 7>(xb, xs, F, T, 4 * t4 - 3);
+        if (!g.active) continue;
+        for (int f4 = g.plane; f4 < F4; f4 += g.PL) {
+            float acc[FC];
+#pragma unroll
+            for (int e = 0; e < FC; ++e) acc[e] = bd[e];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int t2 = 2 * t4 + i - 1;
+                if (t2 < 0 || t2 >= T2) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f2 = 2 * f4 + j - 1;
+                    if (f2 < 0 || f2 >= F2) continue;
+                    float pre[FC], xin[9];
+                    conv0_at(xs, F, 2 * i, f2, w0, b0, pre, xin);
+#pragma unroll
+                    for (int e = 0; e < FC; ++e) acc[e] += wd[i * 3 + j][e] * siluf_(pre[e]);
+                }
+            }
+            store4(d1 + (((long)b * T4 + t4) * F4 + f4) * C + g.c0, acc);
+        }
+    }
+}
+
+// workgroup reduction of NV per-thread sums (4 channels each) over position lanes, then one atomic per value
+template <int NV>
+__device__ __forceinline__ void fused_reduce(const float (&v)[NV][FC], const FGeo& g, int C, float* red, float* out, int out_stride) {
+    const int cgs = C / FC;
+#pragma unroll
+    for (int k = 0; k < NV; ++k)
+#pragma unroll
+        for (int e = 0; e < FC; ++e) {
+            __syncthreads();
+            red[threadIdx.x] = g.active ? v[k][e] : 0.f;
+            __syncthreads();
+            if (g.plane == 0) {
+                float a = 0.f;
+                for (int pl = 0; pl < g.PL; ++pl) a += red[pl * cgs + g.cg];
+                atomicAdd(out + (long)(g.c0 + e) * out_stride + k, a);
+            }
+        }
+}
+
+// dwd[c][i][j] += sum dd1[t4][f4][c] * SiLU(pre0[2t4+i-1][2f4+j-1][c]);  dbd[c] += sum dd1
+template <typename TX>
+__global__ __launch_bounds__(256) void stage01_bwd_dw_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+                                                             const bf16* __restrict__ dd1, float* __restrict__ dwd, float* __restrict__ dbd,
+                                                             int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
+    extern __shared__ float xs[];                        // [7][F] then 256 floats of reduction scratch
+    float* red = xs + 7 * F;
+    const FGeo g(C);
+    const int b = blockIdx.y;
+    float w0[9][FC], b0[FC], gw[9][FC], gb[1][FC];
+#pragma unroll
+    for (int e = 0; e < FC; ++e) {
+        const int c = g.active ? g.c0 + e : 0;
+        b0[e] = b0g[c]; gb[0][e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; gw[k][e] = 0.f; }
+    }
+    const TX* xb = x + (long)b * F * T;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(T4, r0 + rows_per_block);
+    for (int t4 = r0; t4 < r1; ++t4) {
+        stage_mel<TX, 7>(xb, xs, F, T, 4 * t4 - 3);
+        if (!g.active) continue;
+        for (int f4 = g.plane; f4 < F4; f4 += g.PL) {
+            float gv[FC]; load4(dd1 + (((long)b * T4 + t4) * F4 + f4) * C + g.c0, gv);
+#pragma unroll
+            for (int e = 0; e < FC; ++e) gb[0][e] += gv[e];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int t2 = 2 * t4 + i - 1;
+                if (t2 < 0 || t2 >= T2) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int f2 = 2 * f4 + j - 1;
+                    if (f2 < 0 || f2 >= F2) continue;
+                    float pre[FC], xin[9];
+                    conv0_at(xs, F, 2 * i, f2, w0, b0, pre, xin);
+#pragma unroll
+                    for (int e = 0; e < FC; ++e) gw[i * 3 + j][e] += gv[e] * siluf_(pre[e]);
+                }
+            }
+        }
+    }
+    fused_reduce<9>(gw, g, C, red, dwd, 9);
+    fused_reduce<1>(gb, g, C, red, dbd, 1);
+}
+
+// dpre0[t2][f2][c] = SiLU'(pre0) * sum_{(i,j): 2to+i-1=t2, 2fo+j-1=f2} wd[c][i][j] * dd1[to][fo][c]   (never stored)
+// dw0[c][a][b] += sum dpre0 * x[2f2+b-1][2t2+a-1];  db0[c] += sum dpre0
+template <typename TX>
+__global__ __launch_bounds__(256) void stage01_bwd_conv0_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+                                                                const float* __restrict__ wdg, const bf16* __restrict__ dd1,
+                                                                float* __restrict__ dw0, float* __restrict__ db0,
+                                                                int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
+    extern __shared__ float xs[];                        // [3][F] mel | 256 floats reduction scratch | 2 dd1 rows [2][F4][C] bf16
+    float* red = xs + 3 * F;
+    bf16* grow = reinterpret_cast<bf16*>(red + 256);
+    const FGeo g(C);
+    const int b = blockIdx.y;
+    float w0[9][FC], b0[FC], wd[9][FC], gw[9][FC], gb[1][FC];
+#pragma unroll
+    for (int e = 0; e < FC; ++e) {
+        const int c = g.active ? g.c0 + e : 0;
+        b0[e] = b0g[c]; gb[0][e] = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; wd[k][e] = wdg[c * 9 + k]; gw[k][e] = 0.f; }
+    }
+    const TX* xb = x + (long)b * F * T;
+    const bf16* gp = dd1 + (long)b * T4 * F4 * C;
+    const int rowel = F4 * C;                             // elements of one dd1 row
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(T2, r0 + rows_per_block);
+    for (int t2 = r0; t2 < r1; ++t2) {
+        stage_mel<TX, 3>(xb, xs, F, T, 2 * t2 - 1);
+        // the (at most two) dd1 rows this conv0 row feeds: to = (t2 + 1 - i) / 2 for the i of matching parity.
+        // slot 0 <- row floor((t2+1)/2)  [i = 0 (t2 odd) or i = 1 (t2 even)],  slot 1 <- row (t2-1)/2  [i = 2, t2 odd]
+        const int toA = (t2 + 1) >> 1, toB = (t2 - 1) >> 1;
+        for (int idx = threadIdx.x * 8; idx < rowel; idx += 256 * 8) {
+            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+            if (toA < T4) va = *reinterpret_cast<const uint4*>(gp + (long)toA * rowel + idx);
+            if ((t2 & 1) && toB >= 0 && toB < T4) vb = *reinterpret_cast<const uint4*>(gp + (long)toB * rowel + idx);
+            *reinterpret_cast<uint4*>(grow + idx) = va;
+            *reinterpret_cast<uint4*>(grow + rowel + idx) = vb;
+        }
+        __syncthreads();
+        if (!g.active) continue;
+        for (int f2 = g.plane; f2 < F2; f2 += g.PL) {
+            float gs[FC] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int tt = t2 + 1 - i;                     // = 2*to
+                if (tt < 0 || (tt & 1)) continue;
+                if ((tt >> 1) >= T4) continue;
+                const bf16* grw = grow + ((i == 2) ? rowel : 0);   // i = 0/1 -> slot 0, i = 2 -> slot 1
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ff = f2 + 1 - j;
+                    if (ff < 0 || (ff & 1)) continue;
+                    const int fo = ff >> 1;
+                    if (fo >= F4) continue;
+                    float gv[FC]; load4(grw + fo * C + g.c0, gv);
+#pragma unroll
+                    for (int e = 0; e < FC; ++e) gs[e] += wd[i * 3 + j][e] * gv[e];
+                }
+            }
+            float pre[FC], xin[9];
+            conv0_at(xs, F, 0, f2, w0, b0, pre, xin);
+#pragma unroll
+            for (int e = 0; e < FC; ++e) {
+                const float dp = gs[e] * dsiluf_(pre[e]);
+                gb[0][e] += dp;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) gw[k][e] += dp * xin[k];
+            }
+        }
+    }
+    fused_reduce<9>(gw, g, C, red, dw0, 9);
+    fused_reduce<1>(gb, g, C, red, db0, 1);
+}
+
 struct LaunchGeo { int PL, iters, threads; dim3 grid; };
 // npos positions per batch item; aim for ~target workgroups in total.
 inline LaunchGeo geo_for(int64_t C, int64_t B, long npos, long target_blocks) {
@@ -328,5 +558,46 @@ SCONF_API int sconf_sub_silu_transpose(int bwd, const void* pre, const void* ds,
     if (!bwd) hipLaunchKernelGGL((silu_transpose_kernel<false>), dim3(blocks), dim3(256), sh, stream, (const bf16*)pre, (const bf16*)ds, (bf16*)out, (long)rows, (int)F8, (int)C);
     else      hipLaunchKernelGGL((silu_transpose_kernel<true>), dim3(blocks), dim3(256), sh, stream, (const bf16*)pre, (const bf16*)ds, (bf16*)out, (long)rows, (int)F8, (int)C);
     SCONF_LAUNCH_OK("sconf_sub_silu_transpose");
+    return 0;
+}
+
+// Fused subsampler stage 0->1 forward: d1 (B,T4,F4,C) bf16 = dwConv(SiLU(conv0(x))) + bias, no (B,T/2,F/2,C) tensor.
+// Replaces subsampling.py:299-318 (conv[0..2]).
+SCONF_API int sconf_sub_stage01_fwd(const void* x, int x_dtype, const float* w0, const float* b0, const float* wd, const float* bd,
+                                    void* d1, int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream) {
+    SCONF_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconf_sub_stage01_fwd: C must be a multiple of 4 and <= 1024");
+    SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_fwd: B <= 65535 and F <= 1024");
+    const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
+    if (B * T4 * F4 == 0) return 0;
+    const int rpb = std::max(1, (int)cdiv((long)T4 * B, 8192));
+    dim3 grid(cdiv(T4, rpb), (unsigned)B), block(256);
+    const size_t sh = (size_t)7 * F * 4;
+    if (x_dtype == SCONF_F32) hipLaunchKernelGGL((stage01_fwd_kernel<float>), grid, block, sh, stream, (const float*)x, w0, b0, wd, bd, (bf16*)d1, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb);
+    else hipLaunchKernelGGL((stage01_fwd_kernel<bf16>), grid, block, sh, stream, (const bf16*)x, w0, b0, wd, bd, (bf16*)d1, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb);
+    SCONF_LAUNCH_OK("sconf_sub_stage01_fwd");
+    return 0;
+}
+
+// Backward of the fused stage: parameter gradients of conv0 and of the first depthwise conv from dd1 (B,T4,F4,C) bf16;
+// all four outputs ACCUMULATED (+=).  (The mel input needs no gradient.)
+SCONF_API int sconf_sub_stage01_bwd(const void* dd1, const void* x, int x_dtype, const float* w0, const float* b0, const float* wd,
+                                    float* dw0, float* db0, float* dwd, float* dbd, int64_t B, int64_t F, int64_t T, int64_t C,
+                                    hipStream_t stream) {
+    SCONF_REQUIRE(C % 4 == 0 && C / 4 <= 256, "sconf_sub_stage01_bwd: C must be a multiple of 4 and <= 1024");
+    SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_bwd: B <= 65535 and F <= 1024");
+    const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
+    if (B * T4 * F4 == 0) return 0;
+    const int rpb4 = std::max(1, (int)cdiv((long)T4 * B, 1024)), rpb2 = std::max(1, (int)cdiv((long)T2 * B, 1024));
+    dim3 g4(cdiv(T4, rpb4), (unsigned)B), g2(cdiv(T2, rpb2), (unsigned)B), block(256);
+    const size_t sh7 = (size_t)(7 * F + 256) * 4, sh3 = (size_t)(3 * F + 256) * 4 + (size_t)2 * F4 * C * 2;
+    SCONF_REQUIRE(sh3 <= 64 * 1024 && (F4 * C) % 8 == 0, "sconf_sub_stage01_bwd: dd1 rows do not fit LDS");
+    if (x_dtype == SCONF_F32) {
+        hipLaunchKernelGGL((stage01_bwd_dw_kernel<float>), g4, block, sh7, stream, (const float*)x, w0, b0, (const bf16*)dd1, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb4);
+        hipLaunchKernelGGL((stage01_bwd_conv0_kernel<float>), g2, block, sh3, stream, (const float*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2);
+    } else {
+        hipLaunchKernelGGL((stage01_bwd_dw_kernel<bf16>), g4, block, sh7, stream, (const bf16*)x, w0, b0, (const bf16*)dd1, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb4);
+        hipLaunchKernelGGL((stage01_bwd_conv0_kernel<bf16>), g2, block, sh3, stream, (const bf16*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2);
+    }
+    SCONF_LAUNCH_OK("sconf_sub_stage01_bwd");
     return 0;
 }

@@ -331,22 +331,21 @@ class SubsampleFn(Function):
         C = w0.shape[0]
         w0f, wd1f, wd2f = (t.detach().reshape(C, 9).contiguous() for t in (w0, wd1, wd2))
         wp1h, wp2h, woh = wcast(wp1), wcast(wp2), wcast(wout)
-        pre0 = ops.sub_conv0_fwd(audio, w0f, b0)                                       # (B,T2,F2,C)
-        d1 = ops.sub_dwconv_fwd(pre0, wd1f, bd1)                                       # (B,T4,F4,C)
+        d1 = ops.sub_stage01_fwd(audio, w0f, b0, wd1f, bd1)                            # (B,T4,F4,C); stage 0 never hits HBM
         pre1 = ops.gemm(d1.view(-1, C), wp1h, 'nt', bias=bp1).view(d1.shape)
         d2 = ops.sub_dwconv_fwd(pre1, wd2f, bd2)                                       # (B,N,F8,C)
         pre2 = ops.gemm(d2.view(-1, C), wp2h, 'nt', bias=bp2).view(d2.shape)
         N, F8 = d2.shape[1], d2.shape[2]
         s = ops.sub_silu_transpose(pre2.view(B * N, F8, C))                            # (B*N, C*F8)
         x = ops.gemm(s, woh, 'nt', bias=bout, out_dtype=F32)
-        ctx.save_for_backward(audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, pre0, d1, pre1, d2, pre2, s)
+        ctx.save_for_backward(audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s)
         ctx.cfg = (w0.shape, wd1.shape, wp1.shape, wd2.shape, wp2.shape, wout.shape)
         return x.view(B, N, -1)
 
     @staticmethod
     def backward(ctx, dx):
         s0, sd1, sp1, sd2, sp2, so = ctx.cfg
-        audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, pre0, d1, pre1, d2, pre2, s = ctx.saved_tensors
+        audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s = ctx.saved_tensors
         B, N, F8, C = d2.shape
         dev = dx.device
         dx16 = ops.cast(dx.contiguous().view(B * N, -1), BF16)
@@ -363,9 +362,8 @@ class SubsampleFn(Function):
         dbp1 = _bgrad(dpre1, bp1)
         dd1 = ops.gemm(dpre1, wp1h, 'nn').view(d1.shape)
         dwd1 = torch.zeros(C, 9, dtype=F32, device=dev); dbd1 = torch.zeros(C, dtype=F32, device=dev)
-        dpre0 = ops.sub_dwconv_bwd(dd1, wd1f, pre0, dwd1, dbd1)
         dw0 = torch.zeros(C, 9, dtype=F32, device=dev); db0 = torch.zeros(C, dtype=F32, device=dev)
-        ops.sub_conv0_bwd_(dpre0, audio, dw0, db0)
+        ops.sub_stage01_bwd_(dd1, audio, w0f, b0, wd1f, dw0, db0, dwd1, dbd1)          # conv0 recomputed; no (B,T/2,F/2,C) grads
         return (None, dw0.reshape(s0), db0, dwd1.reshape(sd1), dbd1, dwp1, dbp1, dwd2.reshape(sd2), dbd2, dwp2, dbp2, dwo, dbo)
 
 

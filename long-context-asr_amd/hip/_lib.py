@@ -36,6 +36,8 @@ PROTOTYPES = {
     'sconf_sub_dwconv_fwd': [vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_dwconv_bwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_conv0_bwd': [vp, vp, i32, vp, vp, i64, i64, i64, i64, vp],
+    'sconf_sub_stage01_fwd': [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
+    'sconf_sub_stage01_bwd': [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_silu_transpose': [i32, vp, vp, vp, i64, i64, i64, vp],
     'sconf_ctc_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_ctc_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],

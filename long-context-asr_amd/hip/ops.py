@@ -333,6 +333,23 @@ def sub_conv0_bwd_(dpre0: torch.Tensor, x: torch.Tensor, dw: torch.Tensor, dbias
     _lib.call('sconf_sub_conv0_bwd', _p(dpre0), _p(x), _dt(x), _p(dw), _p(dbias), B, F, T, Cc, _stream())
 
 
+def sub_stage01_fwd(x: torch.Tensor, w0: torch.Tensor, b0: torch.Tensor, wd: torch.Tensor, bd: torch.Tensor) -> torch.Tensor:
+    """Fused conv0 + SiLU + first depthwise conv: x (B,F,T) -> d1 (B,T4,F4,C) bf16 (no stage-0 tensor in HBM)."""
+    _chk(x, 'x'); _chk(w0, 'w0', torch.float32); _chk(wd, 'wd', torch.float32)
+    B, F, T = x.shape; Cc = w0.shape[0]
+    d1 = torch.empty(B, _half(_half(T)), _half(_half(F)), Cc, dtype=torch.bfloat16, device=x.device)
+    _lib.call('sconf_sub_stage01_fwd', _p(x), _dt(x), _p(w0), _p(b0), _p(wd), _p(bd), _p(d1), B, F, T, Cc, _stream())
+    return d1
+
+
+def sub_stage01_bwd_(dd1: torch.Tensor, x: torch.Tensor, w0, b0, wd, dw0, db0, dwd, dbd) -> None:
+    """Parameter gradients of the fused stage (accumulated in place) from dd1 (B,T4,F4,C) bf16."""
+    _chk(dd1, 'dd1', torch.bfloat16); _chk(x, 'x')
+    B, F, T = x.shape; Cc = dd1.shape[-1]
+    _lib.call('sconf_sub_stage01_bwd', _p(dd1), _p(x), _dt(x), _p(w0), _p(b0), _p(wd), _p(dw0), _p(db0), _p(dwd), _p(dbd),
+              B, F, T, Cc, _stream())
+
+
 def sub_silu_transpose(pre: torch.Tensor, ds: Optional[torch.Tensor] = None) -> torch.Tensor:
     """fwd (ds None): pre (R,F8,C) -> (R, C*F8) = SiLU(pre) in the reference's c*F8+f order.
     bwd: ds (R, C*F8) -> (R,F8,C) = ds^T * SiLU'(pre)."""

@@ -316,6 +316,24 @@ def sub_conv0_bwd_(dpre0, x, dw, dbias):
     dw += wf.grad.reshape(dw.shape); dbias += bf_.grad
 
 
+def _stage01(x, w0, b0, wd, bd):
+    Cc = w0.shape[0]
+    y0 = F.conv2d(x.to(f32).transpose(1, 2).unsqueeze(1), w0.reshape(Cc, 1, 3, 3), b0, stride=2, padding=1)
+    return F.conv2d(F.silu(y0), wd.reshape(Cc, 1, 3, 3), bd, stride=2, padding=1, groups=Cc).permute(0, 2, 3, 1)
+
+
+def sub_stage01_fwd(x, w0, b0, wd, bd):
+    return _stage01(x, w0, b0, wd, bd).contiguous().to(torch.bfloat16)
+
+
+def sub_stage01_bwd_(dd1, x, w0, b0, wd, dw0, db0, dwd, dbd):
+    ps = [t.detach().clone().requires_grad_(True) for t in (w0, b0, wd)]
+    bdz = torch.zeros_like(b0).requires_grad_(True)
+    with torch.enable_grad():
+        _stage01(x, ps[0], ps[1], ps[2], bdz).backward(dd1.to(f32))
+    dw0 += ps[0].grad.reshape(dw0.shape); db0 += ps[1].grad; dwd += ps[2].grad.reshape(dwd.shape); dbd += bdz.grad
+
+
 def sub_silu_transpose(pre, ds=None):
     R, F8, Cc = pre.shape
     pf = pre.to(f32)

@@ -293,6 +293,16 @@ def test_subsample_ops(ops, B, T, C):
     ops.sub_conv0_bwd_(dev(dprer), dev(x), dw0, db0)
     R.sub_conv0_bwd_(dprer, x, dw0r, db0r)
     close(dw0, dw0r, name='conv0 dw', tol=5e-3); close(db0, db0r, name='conv0 db', tol=5e-3)
+    # fused stage 0 -> 1 (conv0 recomputed from the mel patch; no stage-0 tensor)
+    d1f = ops.sub_stage01_fwd(dev(x), dev(w0), dev(b0), dev(wd), dev(bd))
+    d1fr = R.sub_stage01_fwd(x, w0, b0, wd, bd)
+    close(d1f, d1fr, name='stage01 fwd')
+    gs_ = [torch.zeros(C, 9), torch.zeros(C), torch.zeros(C, 9), torch.zeros(C)]
+    gg_ = [t_.clone().cuda() for t_ in gs_]
+    ops.sub_stage01_bwd_(dev(dout), dev(x), dev(w0), dev(b0), dev(wd), *gg_)
+    R.sub_stage01_bwd_(dout, x, w0, b0, wd, *gs_)
+    for a_, b_, nm in zip(gg_, gs_, ('dw0', 'db0', 'dwd', 'dbd')):
+        close(a_, b_, name='stage01 ' + nm, tol=5e-3)
     pre2 = rnd(B * 7, 10, C, seed=6)
     s = ops.sub_silu_transpose(dev(pre2))
     sr = R.sub_silu_transpose(pre2)
