@@ -41,10 +41,12 @@ PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 M
 
 
 class GemmTimer:
-    """HIP-event timing of every NT GEMM launch (the dominant kernel) on the stream it is launched on."""
+    """HIP-event timing of every NT GEMM launch (the dominant kernel) on the stream it is launched on.
+    Events are created and recorded once BEFORE the timed region (event creation grows a driver pool and stalls the
+    stream for tens of ms when it happens mid-run); inside the timed region events are only re-recorded."""
 
     def __init__(self):
-        self.events, self.flops, self.enabled = [], 0.0, False
+        self.pool, self.used, self.flops, self.enabled, self.count_only, self.calls = [], 0, 0.0, False, False, 0
 
     def install(self):
         import lcasr_amd.hip.ops as ops
@@ -52,25 +54,37 @@ class GemmTimer:
         timer = self
 
         def gemm(a, b, layout='nt', **kw):
-            if not timer.enabled or layout != 'nt':
+            if layout != 'nt' or not (timer.enabled or timer.count_only):
                 return inner(a, b, layout, **kw)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            if timer.count_only:
+                timer.calls += 1
+                return inner(a, b, layout, **kw)
+            if timer.used + 2 > len(timer.pool):
+                return inner(a, b, layout, **kw)
+            e0, e1 = timer.pool[timer.used], timer.pool[timer.used + 1]
+            timer.used += 2
             e0.record()
             out = inner(a, b, layout, **kw)
             e1.record()
-            timer.events.append((e0, e1))
             timer.flops += 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
             return out
         ops.gemm = gemm
 
+    def prepare(self, n_launches):
+        self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_launches)]
+        for e in self.pool:
+            e.record()                                                # force lazy creation now
+        torch.cuda.synchronize()
+
     def summary(self):
-        if not self.events:
+        if not self.used:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1 in self.events)
+        ms = sum(self.pool[i].elapsed_time(self.pool[i + 1]) for i in range(0, self.used, 2))
+        n = self.used // 2
         ach = self.flops / (ms * 1e-3)
         return dict(bound='mfma', kernel='gemm_kernel<NT> (sconf_gemm_bf16 layout 0)', achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
-                    unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=None, launches=len(self.events),
-                    avg_launch_us=round(ms * 1e3 / len(self.events), 2))
+                    unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=None, launches=n,
+                    avg_launch_us=round(ms * 1e3 / n, 2))
 
 
 def host_cores() -> int:
@@ -131,16 +145,25 @@ def main():
     ap.add_argument('--config', default='c3', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--per-step', action='store_true', help='diagnostic: print per-step GPU times (HIP events, no extra syncs)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = int(os.environ.get('LOCAL_RANK', '0'))
     import torch.distributed as dist
+    # rehearsal hook: SCONF_DIST_BACKEND=gloo SCONF_SINGLE_DEVICE=1 runs several ranks on ONE GPU (RCCL refuses duplicate
+    # devices) to exercise the multi-rank code path on a one-GPU box; the driver's real runs use nccl (= RCCL over xGMI).
+    backend = os.environ.get('SCONF_DIST_BACKEND', 'nccl')
+    if os.environ.get('SCONF_SINGLE_DEVICE'):
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device('cuda', local))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, f'--gpus {args.gpus} but WORLD_SIZE={world}'
 
     import lcasr_amd  # noqa: F401
@@ -167,16 +190,30 @@ def main():
         torch.cuda.synchronize()
 
     loss = None
-    for _ in range(args.warmup):
+    timer.count_only = True
+    for i in range(max(args.warmup, 1)):
         loss = trainer.step(audio, lengths, targets, tl)
+        if i == 0:
+            timer.count_only = False
+    timer.prepare(timer.calls * args.steps)
+    import gc
+    gc.collect(); gc.disable()                                       # no collector pauses inside the timed region
     sync()
     timer.enabled = True
     t0 = time.perf_counter()
+    step_ev = []
     for _ in range(args.steps):
+        if args.per_step:
+            e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
         loss = trainer.step(audio, lengths, targets, tl)
+    if args.per_step:
+        e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
     sync()
     dt = time.perf_counter() - t0
+    if args.per_step and rank == 0:
+        print('per-step ms:', [round(a.elapsed_time(b), 1) for a, b in zip(step_ev[:-1], step_ev[1:])], file=sys.stderr)
     timer.enabled = False
+    gc.enable()
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device='cuda')
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

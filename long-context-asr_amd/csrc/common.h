@@ -105,23 +105,27 @@ __device__ __forceinline__ float block_max(float v, float* sh) {
     return r;
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+// Activations on the fast hardware ops (v_exp_f32 = 2^x, v_rcp_f32).  exp2 of a large positive argument gives +inf and
+// rcp(inf) = 0, so the saturated tails are exact without branches.
+__device__ __forceinline__ float sigmoidf_(float x) {
+    return __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
 __device__ __forceinline__ float siluf_(float x) { return x * sigmoidf_(x); }
 __device__ __forceinline__ float dsiluf_(float x) { float s = sigmoidf_(x); return s * (1.f + x * (1.f - s)); }
-__device__ __forceinline__ float tanhf_(float x) {
-    float e = __expf(2.f * x);                     // inf-safe: e=inf -> 1, e=0 -> -1
-    return 1.f - 2.f / (e + 1.f);
-}
-// GELU tanh approximation (reference: F.gelu(approximate='tanh'), fused_dense.py:466)
+__device__ __forceinline__ float tanhf_(float x) { return 2.f * sigmoidf_(2.f * x) - 1.f; }
+// GELU, tanh approximation (reference: F.gelu(approximate='tanh'), fused_dense.py:466).  0.5(1 + tanh(y)) == sigmoid(2y),
+// so  gelu(x) = x * sigmoid(2c(x + 0.044715 x^3)),  c = sqrt(2/pi):  one exp2 + one rcp per element.
 __device__ __forceinline__ float geluf_(float x) {
-    const float c = 0.7978845608028654f;
-    float t = tanhf_(c * (x + 0.044715f * x * x * x));
-    return 0.5f * x * (1.f + t);
+    const float k = -2.f * 0.7978845608028654f * 1.4426950408889634f;         // -2c * log2(e)
+    const float z = x * (1.f + 0.044715f * x * x);
+    return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(k * z));
 }
 __device__ __forceinline__ float dgeluf_(float x) {
-    const float c = 0.7978845608028654f;
-    float t = tanhf_(c * (x + 0.044715f * x * x * x));
-    return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * c * (1.f + 3.f * 0.044715f * x * x);
+    const float c2 = 2.f * 0.7978845608028654f;
+    const float x2 = x * x;
+    const float z = x * (1.f + 0.044715f * x2);
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-c2 * 1.4426950408889634f * z));
+    return s + x * s * (1.f - s) * c2 * (1.f + 3.f * 0.044715f * x2);
 }
 
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

@@ -110,7 +110,7 @@ def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
     if tiles >= slots or nkt < 32:
         return 1
     best, best_cost = 1, None
-    for s_ in range(1, min(32, nkt // 8) + 1):
+    for s_ in range(1, min(128, nkt // 8) + 1):
         items = tiles * s_                                   # (tile, split) work items, walked by <= slots workgroups
         cost = -(-items // min(items, slots)) * (-(-nkt // s_) + (3 if s_ > 1 else 1))
         if best_cost is None or cost < best_cost:
