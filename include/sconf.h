@@ -19,7 +19,8 @@ extern "C" {
 typedef struct ihipStream_t* sconf_stream_t; /* == hipStream_t */
 
 enum { SCONF_F32 = 0, SCONF_BF16 = 1 };
-enum { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4 };
+enum { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4,
+       SCONF_ACT_GELU_DSAVE = 5 /* out = gelu(v), pre = gelu'(v) */, SCONF_ACT_MULAUX = 6 /* out = v * aux */ };
 enum { SCONF_GEMM_NT = 0, SCONF_GEMM_NN = 1, SCONF_GEMM_TN = 2 };
 enum { SCONF_NORM_LAYER = 0, SCONF_NORM_RMS = 1, SCONF_NORM_RMS_APEX = 2 };
 
@@ -52,6 +53,8 @@ int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_
                    float* dbias, int64_t M, int64_t d, float eps, sconf_stream_t stream);
 
 int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
+/* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */
+int sconf_cast_transpose(const float* src, void* dst, int64_t R, int64_t C, sconf_stream_t stream);
 
 /* qkv de-interleave "b n (h d qkv) -> qkv b n h d" + NeoX rotary on q,k (attention.py:485,498-507; rotary_emb.py:61-73).
  * bwd != 0: transpose, (dq,dk,dv) -> dqkv written to `qkv`.  cos/sin: f32 [N][D/2]. */

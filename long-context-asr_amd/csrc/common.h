@@ -21,7 +21,10 @@ int sconf_set_error(const char* fmt, ...);
     if (e_ != hipSuccess) return sconf_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); } while (0)
 
 enum SconfDtype { SCONF_F32 = 0, SCONF_BF16 = 1 };
-enum SconfAct { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4 };
+enum SconfAct { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4,
+                SCONF_ACT_GELU_DSAVE = 5,   // out = gelu(v); `pre` receives gelu'(v) (what the backward multiplies by)
+                SCONF_ACT_MULAUX = 6 };     // out = v * aux
+
 
 // ---- device helpers --------------------------------------------------------------------------
 __device__ __forceinline__ float bf2f(bf16 x) { return (float)x; }
@@ -119,6 +122,15 @@ __device__ __forceinline__ float geluf_(float x) {
     const float k = -2.f * 0.7978845608028654f * 1.4426950408889634f;         // -2c * log2(e)
     const float z = x * (1.f + 0.044715f * x * x);
     return x * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(k * z));
+}
+// gelu(x) and gelu'(x) sharing the one sigmoid (forward epilogue that saves the derivative for the backward)
+__device__ __forceinline__ void gelu_both(float x, float& g, float& dg) {
+    const float c2 = 2.f * 0.7978845608028654f;
+    const float x2 = x * x;
+    const float z = x * (1.f + 0.044715f * x2);
+    const float s = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-c2 * 1.4426950408889634f * z));
+    g = x * s;
+    dg = s + g * (1.f - s) * c2 * (1.f + 3.f * 0.044715f * x2);
 }
 __device__ __forceinline__ float dgeluf_(float x) {
     const float c2 = 2.f * 0.7978845608028654f;

@@ -19,6 +19,25 @@ __global__ void cast_bf16_f32_kernel(const bf16* __restrict__ s, float* __restri
     if (i < n) for (long j = i; j < n && j < i + 8; ++j) d[j] = (float)s[j];
 }
 
+// dst[c][r] = bf16(src[r][c]): transposed bf16 shadow of an f32 weight (so every dgrad is an NT GEMM whose B operand
+// is K-contiguous); 32x32 tiles through LDS, both sides coalesced.
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __restrict__ src, bf16* __restrict__ dst, int R, int C) {
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        tile[ty + 8 * k][tx] = (r < R && c < C) ? src[(long)r * C + c] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < R) dst[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // qkv de-interleave + NeoX rotary.  Reference layout of the qkv projection output is
 // "b n (h d qkv)" (attention.py:485): column (h*D + d)*3 + {0:q, 1:k, 2:v}.  One thread handles
@@ -194,6 +213,14 @@ SCONF_API int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtyp
     if (src_dtype == SCONF_F32) hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(blocks), dim3(256), 0, stream, (const float*)src, (bf16*)dst, (long)n);
     else hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(blocks), dim3(256), 0, stream, (const bf16*)src, (float*)dst, (long)n);
     SCONF_LAUNCH_OK("sconf_cast");
+    return 0;
+}
+
+// dst (C,R) bf16 = transpose(src (R,C) f32)
+SCONF_API int sconf_cast_transpose(const float* src, void* dst, int64_t R, int64_t C, hipStream_t stream) {
+    if (R * C == 0) return 0;
+    hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream, src, (bf16*)dst, (int)R, (int)C);
+    SCONF_LAUNCH_OK("sconf_cast_transpose");
     return 0;
 }
 

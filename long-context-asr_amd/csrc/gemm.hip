@@ -45,6 +45,11 @@ struct GemmParams {
 };
 
 __device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+// XOR swizzle (in 16-B chunks) of a K-contiguous tile row.  The A image is read 16 consecutive rows at a time; the B
+// image is read with the PERMUTED row set {16p + 4j + e} (see tile_mma), so it needs a different conflict-free function.
+template <bool BIMG> __device__ __forceinline__ int swz_kc(int row) {
+    return BIMG ? (((row >> 1) & 1) | (((row >> 4) & 3) << 1)) : ((row >> 1) & 7);
+}
 
 // ---- global -> register staging of one 128 x 64 operand tile (4 x 16 B per thread) ----------
 template <bool KS>
@@ -67,7 +72,7 @@ __device__ __forceinline__ void tile_gload(uint4 (&r)[4], const bf16* __restrict
     }
 }
 
-template <bool KS>
+template <bool KS, bool BIMG>
 __device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int tid) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -75,7 +80,7 @@ __device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int ti
         int off;
         if (!KS) {
             const int row = c >> 3, kc = c & 7;
-            off = row * 128 + ((kc ^ ((row >> 1) & 7)) << 4);
+            off = row * 128 + ((kc ^ swz_kc<BIMG>(row)) << 4);
         } else {
             const int kr = c >> 4, rc = c & 15;
             off = kr * 256 + ((rc ^ swz_strided(kr)) << 4);
@@ -92,14 +97,14 @@ __device__ __forceinline__ void tile_lstore(const uint4 (&r)[4], char* s, int ti
 // Per-lane byte offsets of a tile's 4 chunks are loop-invariant over K: computed once per tile (GldsOffs), while the
 // K advance lives in the wave-uniform (SGPR) base pointer, so the staging address math costs no VALU per K-step
 // (global_load_lds saddr + 32-bit voffset form).
-template <bool KS> struct GldsOffs {
+template <bool KS, bool BIMG> struct GldsOffs {
     unsigned off[4];
     __device__ __forceinline__ void set(long ld, int rows, int row0, int tid) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int c = tid + 256 * i;
             if (!KS) {
-                const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
+                const int row = c >> 3, p = c & 7, kc = p ^ swz_kc<BIMG>(row);
                 off[i] = (unsigned)(((long)min(row0 + row, rows - 1) * ld + kc * 8) * 2);
             } else {
                 const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
@@ -108,8 +113,8 @@ template <bool KS> struct GldsOffs {
         }
     }
 };
-template <bool KS>
-__device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, int k0, const GldsOffs<KS>& o, char* s, int tid) {
+template <bool KS, bool BIMG>
+__device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, int k0, const GldsOffs<KS, BIMG>& o, char* s, int tid) {
     typedef const __attribute__((address_space(1))) void* gptr;
     typedef __attribute__((address_space(3))) void* lptr;
     const char* base = reinterpret_cast<const char*>(P) + (KS ? (long)k0 * ld * 2 : (long)k0 * 2);   // wave-uniform
@@ -118,62 +123,147 @@ __device__ __forceinline__ void tile_glds(const bf16* __restrict__ P, long ld, i
         __builtin_amdgcn_global_load_lds((gptr)(base + o.off[i]), (lptr)(s + ((tid & ~63) + 256 * i) * 16), 16, 0, 0);
 }
 
-// ---- LDS -> MFMA fragment: 16 rows [rbase, rbase+16) x 32 k of k-step kk --------------------
-template <bool KS>
-__device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int kk, int lane) {
+// ---- LDS -> MFMA fragment, 16 rows x 32 k of k-step kk ------------------------------------------------------------
+// A operand (BIMG = false): rows rbase + (0..15).
+// B operand, K-contiguous (BIMG = true, NT layout): PERMUTED rows  wbase + 16*(r>>2) + 4*j + (r&3),  r = 0..15, for
+//   column tile j of the wave's 64 columns.  (A K-strided B keeps natural columns: the permuted transposed read would be
+//   2-way bank-conflicted, measured -9 % on the wgrad shapes; those kernels use the narrow epilogue.)  With the MFMA issued operand-swapped, lane (r = lane&15 -> output row m, g = lane>>4) then accumulates
+//   columns wbase + 16*g + 4*j + (0..3) in tile j: over j = 0..3 that is 16 CONSECUTIVE output columns per lane, so the
+//   epilogue moves 32 B (bf16) / 64 B (f32) per lane and 128-256 B per row per wave instead of 8-B pieces.
+template <bool KS, bool BIMG>
+__device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int j, int kk, int lane) {
     if (!KS) {
-        const int r = rbase + (lane & 15), c = kk * 4 + (lane >> 4);
-        return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ ((r >> 1) & 7)) << 4));
+        const int rl = lane & 15;
+        const int r = BIMG ? rbase + ((rl >> 2) << 4) + 4 * j + (rl & 3) : rbase + 16 * j + rl;
+        const int c = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ swz_kc<BIMG>(r)) << 4));
     } else {
         const int i = lane & 15, q = i >> 2, p = i & 3, g = lane >> 4;
-        const int chunk = (rbase >> 3) + (p >> 1);
+        // 16-B chunk and 8-B half of the 4 consecutive rows this lane addresses for the transposed read
+        const int col = rbase + 16 * j + 4 * p;               // strided operands keep the natural column order (see epilogue)
+        const int chunk = col >> 3, sub = (col & 4) * 2;
         const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
         typedef __attribute__((address_space(3))) bf16x4* lds_p;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (lds_p)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + (p & 1) * 8));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16(
-            (lds_p)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + (p & 1) * 8));
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub));
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
 
-// ---- epilogue: lane owns row m, columns n..n+3 of each 16x16 tile ---------------------------------------------
-__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
+// ---- narrow epilogue (K-strided B: NN / TN): lane owns row m and 4 consecutive columns of each 16x16 tile --------------
+__device__ __forceinline__ void gemm_epilogue_narrow(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
+    const int nb = n0 + wn * 64 + (lane >> 4) * 4;
+    const bool dact = p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + (lane & 15);
         if (m >= p.M) continue;
+        bf16x4 ax[4];
+        float4 rs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + (lane >> 4) * 4;
+        for (int j = 0; j < 4; ++j) {                          // phase 1: loads
+            const int n = nb + j * 16;
+            ax[j] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+            rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < p.N) {
+                if (dact) ax[j] = *reinterpret_cast<const bf16x4*>(p.aux + (long)m * p.ldaux + n);
+                if (p.resid) rs[j] = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {                          // phase 2: math + stores
+            const int n = nb + j * 16;
             if (n >= p.N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (p.bias) {
-                float b[4]; load4(p.bias + n, b);
+                float bs[4]; load4(p.bias + n, bs);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += b[e];
+                for (int e = 0; e < 4; ++e) v[e] += bs[e];
             }
-            if (p.pre) store4(p.pre + (long)m * p.ldpre + n, v);
-            if (p.act == SCONF_ACT_GELU) {
+            if (p.act == SCONF_ACT_GELU_DSAVE) {
+                float dg[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], dg[e]);
+                store4(p.pre + (long)m * p.ldpre + n, dg);
+            } else if (p.pre) store4(p.pre + (long)m * p.ldpre + n, v);
+            if (p.act == SCONF_ACT_MULAUX) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] *= (float)ax[j][e];
+            } else if (p.act == SCONF_ACT_GELU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = geluf_(v[e]);
             } else if (p.act == SCONF_ACT_SILU) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = siluf_(v[e]);
-            } else if (p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU) {
-                float a[4]; load4(p.aux + (long)m * p.ldaux + n, a);
+            } else if (dact) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= (p.act == SCONF_ACT_DGELU ? dgeluf_(a[e]) : dsiluf_(a[e]));
+                for (int e = 0; e < 4; ++e) v[e] *= (p.act == SCONF_ACT_DGELU ? dgeluf_((float)ax[j][e]) : dsiluf_((float)ax[j][e]));
             }
+            const float r[4] = {rs[j].x, rs[j].y, rs[j].z, rs[j].w};
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= p.alpha;
-            if (p.resid) {
-                float r[4]; load4(p.resid + (long)m * p.ldr + n, r);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += r[e];
-            }
+            for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + r[e];
             if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
             else           store4(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
+        }
+    }
+}
+
+// ---- epilogue: lane (r = lane&15, g = lane>>4) owns, for each row block i, row m = .. + 16i + r and the 16 consecutive
+// columns n = n0 + 64*wn + 16*g + (0..15): acc[i][j][e] is column 4j + e of that run.  All loads of a row block
+// (aux / residual) are issued before its math and stores.
+__device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
+    const int nrun = n0 + wn * 64 + (lane >> 4) * 16;
+    if (nrun >= p.N) return;                                // N % 16 == 0 (host-checked): the 16-column run is all-in or all-out
+    const bool dact = p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        // the run is handled as two 8-column halves (16 B of bf16 / 32 B of f32 per lane each) to bound live registers;
+        // both halves' loads are issued first
+        float ax[2][8], rs[2][8];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            if (dact) load8(p.aux + (long)m * p.ldaux + nrun + 8 * hh, ax[hh]);
+            if (p.resid) load8(p.resid + (long)m * p.ldr + nrun + 8 * hh, rs[hh]);
+        }
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int n = nrun + 8 * hh;
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * hh + (e >> 2)][e & 3];
+            if (p.bias) {
+                float bs[8]; load8(p.bias + n, bs);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bs[e];
+            }
+            if (p.act == SCONF_ACT_GELU_DSAVE) {
+                float dg[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) gelu_both(v[e], v[e], dg[e]);
+                store8(p.pre + (long)m * p.ldpre + n, dg);
+            } else if (p.pre) store8(p.pre + (long)m * p.ldpre + n, v);
+            if (p.act == SCONF_ACT_MULAUX) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= ax[hh][e];
+            } else if (p.act == SCONF_ACT_GELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = geluf_(v[e]);
+            } else if (p.act == SCONF_ACT_SILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = siluf_(v[e]);
+            } else if (p.act == SCONF_ACT_DGELU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dgeluf_(ax[hh][e]);
+            } else if (p.act == SCONF_ACT_DSILU) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= dsiluf_(ax[hh][e]);
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + (p.resid ? rs[hh][e] : 0.f);
+            if (p.out_f32) store8(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
+            else           store8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
         }
     }
 }
@@ -208,9 +298,9 @@ __device__ __forceinline__ void tile_mma(const char* sA, const char* sB, f32x4 (
     for (int kk = 0; kk < 2; ++kk) {
         bf16x8 af[4], bfr[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) af[i] = frag_read<AKS>(sA, wm * 64 + i * 16, kk, lane);
+        for (int i = 0; i < 4; ++i) af[i] = frag_read<AKS, false>(sA, wm * 64, i, kk, lane);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BKS>(sB, wn * 64 + j * 16, kk, lane);
+        for (int j = 0; j < 4; ++j) bfr[j] = frag_read<BKS, true>(sB, wn * 64, j, kk, lane);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -244,10 +334,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
     WorkItem w = tile_coords(p, v, total, ntiles, tiles_m, tiles_n);
 
     if (GLDS) {
-        GldsOffs<AKS> oa; GldsOffs<BKS> ob;
+        GldsOffs<AKS, false> oa; GldsOffs<BKS, true> ob;
         oa.set(p.lda, p.M, w.m0, tid); ob.set(p.ldb, p.N, w.n0, tid);
-        tile_glds<AKS>(p.A, p.lda, w.kbeg, oa, smem, tid);
-        tile_glds<BKS>(p.B, p.ldb, w.kbeg, ob, smem + TILE_BYTES, tid);
+        tile_glds<AKS, false>(p.A, p.lda, w.kbeg, oa, smem, tid);
+        tile_glds<BKS, true>(p.B, p.ldb, w.kbeg, ob, smem + TILE_BYTES, tid);
         __syncthreads();                                     // hipcc drains the LDS-DMA (vmcnt(0)) before the barrier
         int cur = 0;
         while (true) {
@@ -259,16 +349,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
                 const char* sA = smem + cur * 2 * TILE_BYTES;
                 char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
                 if (kt + 1 < nkt) {                          // next K-tile streams into the other buffer during the MFMAs
-                    tile_glds<AKS>(p.A, p.lda, w.kbeg + (kt + 1) * BK, oa, dA, tid);
-                    tile_glds<BKS>(p.B, p.ldb, w.kbeg + (kt + 1) * BK, ob, dA + TILE_BYTES, tid);
+                    tile_glds<AKS, false>(p.A, p.lda, w.kbeg + (kt + 1) * BK, oa, dA, tid);
+                    tile_glds<BKS, true>(p.B, p.ldb, w.kbeg + (kt + 1) * BK, ob, dA + TILE_BYTES, tid);
                 } else if (vn < total) {                     // ... or the NEXT work item's first K-tile
                     oa.set(p.lda, p.M, wn_.m0, tid); ob.set(p.ldb, p.N, wn_.n0, tid);
-                    tile_glds<AKS>(p.A, p.lda, wn_.kbeg, oa, dA, tid);
-                    tile_glds<BKS>(p.B, p.ldb, wn_.kbeg, ob, dA + TILE_BYTES, tid);
+                    tile_glds<AKS, false>(p.A, p.lda, wn_.kbeg, oa, dA, tid);
+                    tile_glds<BKS, true>(p.B, p.ldb, wn_.kbeg, ob, dA + TILE_BYTES, tid);
                 }
                 tile_mma<AKS, BKS>(sA, sA + TILE_BYTES, acc, wm, wn, lane);
                 if (kt == nkt - 1) {
-                    gemm_epilogue(p, acc, w.m0, w.n0, w.split, wm, wn, lane);
+                    if (BKS) gemm_epilogue_narrow(p, acc, w.m0, w.n0, w.split, wm, wn, lane);
+                    else     gemm_epilogue(p, acc, w.m0, w.n0, w.split, wm, wn, lane);
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -286,8 +377,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
         uint4 ra[4], rb[4];
         tile_gload<AKS>(ra, p.A, p.lda, p.M, m0, kbeg, kend, tid);
         tile_gload<BKS>(rb, p.B, p.ldb, p.N, n0, kbeg, kend, tid);
-        tile_lstore<AKS>(ra, smem, tid);
-        tile_lstore<BKS>(rb, smem + TILE_BYTES, tid);
+        tile_lstore<AKS, false>(ra, smem, tid);
+        tile_lstore<BKS, true>(rb, smem + TILE_BYTES, tid);
         __syncthreads();
         for (int kt = 0; kt < nkt; ++kt) {
             const int cur = kt & 1;
@@ -299,129 +390,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmParams p) {
             tile_mma<AKS, BKS>(sA, sA + TILE_BYTES, acc, wm, wn, lane);
             if (kt + 1 < nkt) {                              // write late, into the other buffer
                 char* dA = smem + (cur ^ 1) * 2 * TILE_BYTES;
-                tile_lstore<AKS>(ra, dA, tid);
-                tile_lstore<BKS>(rb, dA + TILE_BYTES, tid);
+                tile_lstore<AKS, false>(ra, dA, tid);
+                tile_lstore<BKS, true>(rb, dA + TILE_BYTES, tid);
             }
             __syncthreads();
         }
-        gemm_epilogue(p, acc, m0, n0, w.split, wm, wn, lane);
+        if (BKS) gemm_epilogue_narrow(p, acc, m0, n0, w.split, wm, wn, lane);
+        else     gemm_epilogue(p, acc, m0, n0, w.split, wm, wn, lane);
     }
-}
-
-// =================================================================================================================
-// Deep-pipelined variant: 256x128x64 block tile, 8 waves (4x2, each 64x64), ONE workgroup per CU, 3-stage LDS ring
-// (3 x 48 KiB), LDS-DMA prefetch distance 2 with a COUNTED s_waitcnt vmcnt(6) and a raw s_barrier per K-step, so two
-// K-steps of loads stay in flight across every barrier (the 2-stage kernel above drains to vmcnt(0) each step).
-// Persistent over (tile, split) work items with the same XCD/L2-patch ordering; the prefetch cursor runs two steps
-// ahead of the compute cursor across item boundaries.  Every step issues exactly 6 LDS-DMA instructions per lane
-// (A: 2 sub-tiles x 2, B: 2) — past the last step the cursor stays clamped and re-loads into the free ring slot —
-// so the wait count is a constant.  Epilogue stores are also VMEM ops: they only make the wait conservative.
-// =================================================================================================================
-constexpr int BM3 = 256, STAGE3 = 3 * TILE_BYTES;      // A: 2 sub-tiles of 128 rows (32 KiB) | B: 16 KiB
-
-template <bool KS> struct Offs512 {                    // 128-row sub-tile, 512 threads -> 2 chunks per thread
-    unsigned off[2];
-    __device__ __forceinline__ void set(long ld, int rows, int row0, int tid) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int c = tid + 512 * i;
-            if (!KS) {
-                const int row = c >> 3, p = c & 7, kc = p ^ ((row >> 1) & 7);
-                off[i] = (unsigned)(((long)min(row0 + row, rows - 1) * ld + kc * 8) * 2);
-            } else {
-                const int kr = c >> 4, p = c & 15, rc = p ^ swz_strided(kr);
-                off[i] = (unsigned)(((long)kr * ld + min(row0 + rc * 8, rows - 8)) * 2);
-            }
-        }
-    }
-};
-template <bool KS>
-__device__ __forceinline__ void sub_glds(const bf16* __restrict__ P, long ld, int k0, const Offs512<KS>& o, char* s, int tid) {
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-    const char* base = reinterpret_cast<const char*>(P) + (KS ? (long)k0 * ld * 2 : (long)k0 * 2);   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        __builtin_amdgcn_global_load_lds((gptr)(base + o.off[i]), (lptr)(s + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
-}
-
-__device__ __forceinline__ WorkItem tile_coords3(const GemmParams& p, int v, int total, int ntiles, int tiles_m, int tiles_n) {
-    const int qx = total >> 3, rx = total & 7, xcd = v & 7;
-    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (v >> 3);
-    const int split = lid / ntiles, t = lid - split * ntiles;
-    constexpr int GM3 = 4;                               // 4 row panels of 256 = the same 1024-row L2 patch as GM=8 x 128
-    const int per_group = GM3 * tiles_n;
-    const int g = t / per_group, r = t - g * per_group;
-    const int first_m = g * GM3, gm = min(GM3, tiles_m - first_m);
-    WorkItem w;
-    w.m0 = (first_m + r % gm) * BM3; w.n0 = (r / gm) * BN;
-    w.split = split;
-    w.kbeg = split * p.k_per_split; w.kend = min(p.K, w.kbeg + p.k_per_split);
-    return w;
-}
-
-template <bool AKS, bool BKS>
-__global__ __launch_bounds__(512, 2) void gemm_kernel3(const GemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [3][A0 16K | A1 16K | B 16K]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;             // wm 0..3
-    const int tiles_n = (p.N + BN - 1) / BN, tiles_m = (p.M + BM3 - 1) / BM3;
-    const int ntiles = tiles_m * tiles_n, total = ntiles * p.splits;
-
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    int cv = blockIdx.x;                                 // compute cursor
-    if (cv >= total) return;
-    WorkItem cw = tile_coords3(p, cv, total, ntiles, tiles_m, tiles_n);
-    int ckt = 0, cnkt = (cw.kend - cw.kbeg) / BK;
-
-    int pv = cv; WorkItem pw = cw; int pkt = 0, pnkt = cnkt;   // prefetch cursor (2 steps ahead)
-    Offs512<AKS> oa0, oa1; Offs512<BKS> ob;
-    auto set_offs = [&]() { oa0.set(p.lda, p.M, pw.m0, tid); oa1.set(p.lda, p.M, pw.m0 + 128, tid); ob.set(p.ldb, p.N, pw.n0, tid); };
-    auto issue = [&](int slot) {
-        char* d = smem + slot * STAGE3;
-        const int k0 = pw.kbeg + pkt * BK;
-        sub_glds<AKS>(p.A, p.lda, k0, oa0, d, tid);
-        sub_glds<AKS>(p.A, p.lda, k0, oa1, d + TILE_BYTES, tid);
-        sub_glds<BKS>(p.B, p.ldb, k0, ob, d + 2 * TILE_BYTES, tid);
-    };
-    auto advance = [&]() {
-        if (pkt + 1 < pnkt) { ++pkt; return; }
-        const int vn = pv + gridDim.x;
-        if (vn < total) { pv = vn; pw = tile_coords3(p, pv, total, ntiles, tiles_m, tiles_n); pkt = 0; pnkt = (pw.kend - pw.kbeg) / BK; set_offs(); }
-        // else: stay clamped on the last step (harmless re-load into the free ring slot keeps the wait count constant)
-    };
-    set_offs();
-    issue(0); advance();
-    issue(1); advance();
-
-    int slot = 0;
-    while (true) {
-        // tile for this step has landed for THIS wave when at most the 6 youngest VMEM ops (next step's DMA) are pending;
-        // the barrier then makes every wave's share visible and frees the slot that step+2 is about to overwrite.
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        int pslot = slot + 2; if (pslot >= 3) pslot -= 3;
-        issue(pslot); advance();
-        const char* sA = smem + slot * STAGE3 + (wm >> 1) * TILE_BYTES;
-        const char* sB = smem + slot * STAGE3 + 2 * TILE_BYTES;
-        tile_mma<AKS, BKS>(sA, sB, acc, wm & 1, wn, lane);
-        if (++slot == 3) slot = 0;
-        if (++ckt == cnkt) {
-            gemm_epilogue(p, acc, cw.m0 + (wm >> 1) * 128, cw.n0, cw.split, wm & 1, wn, lane);
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int vn = cv + gridDim.x;
-            if (vn >= total) break;
-            cv = vn; cw = tile_coords3(p, cv, total, ntiles, tiles_m, tiles_n); ckt = 0; cnkt = (cw.kend - cw.kbeg) / BK;
-        }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // no LDS-DMA may outlive the workgroup's LDS allocation
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int splits, long n, int accumulate) {
@@ -454,6 +430,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     SCONF_REQUIRE(M > 0 && N > 0 && K > 0, "sconf_gemm_bf16: empty problem %ld x %ld x %ld", (long)M, (long)N, (long)K);
     SCONF_REQUIRE(M < (1L << 31) && N < (1L << 31) && K < (1L << 31), "sconf_gemm_bf16: dims must be < 2^31");
     SCONF_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "sconf_gemm_bf16: N and ldc must be multiples of 4 (N=%ld ldc=%ld)", (long)N, (long)ldc);
+    if (layout == 0) SCONF_REQUIRE(N % 16 == 0 && ldc % 8 == 0, "sconf_gemm_bf16: the NT layout needs N %% 16 == 0 and ldc %% 8 == 0 (N=%ld ldc=%ld)", (long)N, (long)ldc);
     const bool aks = layout == 2, bks = layout >= 1;
     // 16-byte global loads: contiguous dim must be a multiple of 8 elements
     SCONF_REQUIRE(lda % 8 == 0 && ldb % 8 == 0, "sconf_gemm_bf16: lda/ldb must be multiples of 8");
@@ -464,7 +441,9 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     else      SCONF_REQUIRE(N % 8 == 0, "sconf_gemm_bf16: N must be a multiple of 8 for K-strided B");
     SCONF_REQUIRE(split_k >= 1, "sconf_gemm_bf16: split_k must be >= 1");
     SCONF_REQUIRE(split_k == 1 || out_f32, "sconf_gemm_bf16: split-K writes f32 partial slabs and needs out_f32");
-    if (act == SCONF_ACT_DGELU || act == SCONF_ACT_DSILU) SCONF_REQUIRE(aux != nullptr, "sconf_gemm_bf16: dact epilogue needs aux");
+    if (act == SCONF_ACT_DGELU || act == SCONF_ACT_DSILU || act == SCONF_ACT_MULAUX) SCONF_REQUIRE(aux != nullptr, "sconf_gemm_bf16: aux epilogue needs aux");
+    if (act == SCONF_ACT_GELU_DSAVE) SCONF_REQUIRE(pre != nullptr, "sconf_gemm_bf16: GELU_DSAVE needs the pre buffer");
+    SCONF_REQUIRE(act >= 0 && act <= 6, "sconf_gemm_bf16: bad act %d", act);
 
     GemmParams p;
     p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C;
@@ -495,26 +474,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     // operands addressable with 32-bit byte offsets from a uniform base.
     const bool glds = !no_glds && K % BK == 0 && M >= 8 && N >= 8 &&
                       (long)(aks ? K : M) * lda * 2 < (1L << 32) && (long)(bks ? K : N) * ldb * 2 < (1L << 32);
-    // The deep-pipelined 256x128 kernel measured no better than the 2-stage 128x128 one on this workload (it wins
-    // ~9 % on long-K NT shapes, loses 10-20 % on the NN/TN shapes), i.e. the 2-stage kernel is not latency-bound:
-    // it stays opt-in for experiments.
-    static bool use_v3 = getenv("SCONF_GEMM_V3") != nullptr;
-    if (glds && use_v3 && M >= 256) {
-        static bool a3 = false;
-        if (!a3) {
-            (void)hipFuncSetAttribute((const void*)gemm_kernel3<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
-            (void)hipFuncSetAttribute((const void*)gemm_kernel3<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
-            (void)hipFuncSetAttribute((const void*)gemm_kernel3<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE3);
-            a3 = true;
-        }
-        static int cus = 0;
-        if (!cus) { int n = sconf_num_cus(); cus = n > 0 ? n : 256; }
-        const int nt3 = cdiv(M, BM3) * cdiv(N, BN);
-        dim3 g3(std::min(nt3 * splits, cus)), b3(512);
-        if (layout == 0)      hipLaunchKernelGGL((gemm_kernel3<false, false>), g3, b3, 3 * STAGE3, stream, p);
-        else if (layout == 1) hipLaunchKernelGGL((gemm_kernel3<false, true>), g3, b3, 3 * STAGE3, stream, p);
-        else                  hipLaunchKernelGGL((gemm_kernel3<true, true>), g3, b3, 3 * STAGE3, stream, p);
-    } else if (glds) {
+    if (glds) {
         static int slots = 0;
         if (!slots) { int n = sconf_num_cus(); slots = 2 * (n > 0 ? n : 256); }
         grid.x = std::min(ntiles * splits, slots);                // persistent: <= 2 resident workgroups per CU

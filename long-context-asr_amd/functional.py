@@ -5,8 +5,9 @@ Each block is ONE ``torch.autograd.Function`` covering a residual branch of the 
   * the residual stream stays f32 (what bf16-autocast gives the reference: LayerNorm outputs f32 and
     ``bf16 + f32 -> f32``), every GEMM operand is bf16 and accumulates in f32;
   * bias / GELU / GLU / residual / 0.5-scale live in GEMM epilogues or in the neighbouring HBM-bound kernel;
-  * the backward fuses the residual gradient into the norm backward (dx = dy + norm'(..)) and never
-    transposes an activation or a weight in HBM (NN / TN GEMM layouts).
+  * the backward fuses the residual gradient into the norm backward (dx = dy + norm'(..)) and never transposes an
+    ACTIVATION in HBM: wgrad is a TN GEMM (hardware transposed LDS reads), dgrad is an NT GEMM against a transposed bf16
+    shadow of the (few-MB) weight, cast once per forward.
 
 Parameters stay f32 masters in the reference's ``state_dict`` layout; a bf16 copy is cast once per forward
 (``wcast``) and reused by the backward.
@@ -36,6 +37,17 @@ def wcast(w: torch.Tensor) -> torch.Tensor:
     t = _wcache.get(key)
     if t is None:
         t = ops.cast(w.detach().reshape(w.shape[0], -1), BF16)
+        _wcache[key] = t
+    return t
+
+
+def wcast_t(w: torch.Tensor) -> torch.Tensor:
+    """Transposed bf16 copy (in_features*k, out_features) of an f32 master weight: dgrad dx = dy W becomes the NT GEMM
+    dy (W^T)^T whose B operand is K-contiguous (wide epilogue, no transposed LDS reads).  Weights are a few MB."""
+    key = ('t', w.data_ptr(), tuple(w.shape))
+    t = _wcache.get(key)
+    if t is None:
+        t = ops.cast_transpose(w.detach().reshape(w.shape[0], -1).contiguous())
         _wcache[key] = t
     return t
 
@@ -94,12 +106,13 @@ class FFBlockFn(Function):
         x = x.contiguous()
         h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
         w1h, w2h = wcast(w1), wcast(w2)
-        a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu', save_pre=True)
+        a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu_dsave', save_pre=True)   # u := gelu'(pre-activation), bf16
         y = ops.gemm(a, w2h, 'nt', bias=b2, resid=x if residual else None, alpha=scale, out_dtype=F32)
+        w1t, w2t = wcast_t(w1), wcast_t(w2)
         if ckpt >= 1:                       # checkpoint_lvl 1/2 (fused_dense.py:283-289): recompute in backward
-            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2)
+            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t)
         else:
-            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, h, u, a)
+            ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t, h, u, a)
         ctx.cfg = (scale, mode, eps, ckpt, w1.shape, w2.shape, residual)
         return y
 
@@ -107,20 +120,20 @@ class FFBlockFn(Function):
     def backward(ctx, dy):
         scale, mode, eps, ckpt, w1s, w2s, residual = ctx.cfg
         t = ctx.saved_tensors
-        x, nw, nb, mean, rstd, w1h, w2h, b1, b2 = t[:9]
+        x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t = t[:11]
         if ckpt >= 1:
             h, _, _ = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
-            a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu', save_pre=True)
+            a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu_dsave', save_pre=True)
         else:
-            h, u, a = t[9:]
+            h, u, a = t[11:]
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
-        du = ops.gemm(dy16, w2h, 'nn', aux=u, act='dgelu', alpha=scale)            # (M,4d)
+        du = ops.gemm(dy16, w2t, 'nt', aux=u, act='mulaux', alpha=scale)           # (M,4d): dy W2 * gelu'(pre)
         dw2 = _wgrad(dy16, a, w2s, alpha=scale)
         db2 = _bgrad(dy16, b2, alpha=scale)
         dw1 = _wgrad(du, h, w1s)
         db1 = _bgrad(du, b1)
-        dh = ops.gemm(du, w1h, 'nn')
+        dh = ops.gemm(du, w1t, 'nt')
         dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
         dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
         return dx, dnw, dnb, dw1, dw2, db1, db2, None, None, None, None, None
@@ -147,25 +160,25 @@ class AttnBlockFn(Function):
         q, k, v = ops.rotary_qkv_fwd(qkv, cos, sin, B, N, H, D)
         o, lse = ops.attn_fwd(q, k, v, lengths, window)                               # padded query rows come back zero
         y = ops.gemm(o.view(B * N, H * D), woh, 'nt', bias=bout, resid=x if residual else None, out_dtype=F32)
-        ctx.save_for_backward(x, nw, nb, mean, rstd, wqh, woh, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wqkv), wcast_t(wout), bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse)
         ctx.cfg = (B, N, H, D, window, mode, eps, wqkv.shape, wout.shape, residual)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, N, H, D, window, mode, eps, wqs, wos, residual = ctx.cfg
-        x, nw, nb, mean, rstd, wqh, woh, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
+        x, nw, nb, mean, rstd, wqt, wot, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
         o2 = o.view(B * N, H * D)
-        do = ops.gemm(dy16, woh, 'nn')                                                # (M, H*D)
+        do = ops.gemm(dy16, wot, 'nt')                                                # (M, H*D)
         dwo = _wgrad(dy16, o2, wos)
         dbo = _bgrad(dy16, bout)
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, lengths, window)
         dqkv = ops.rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D)
         dwq = _wgrad(dqkv, h, wqs)
         dbq = _bgrad(dqkv, bqkv)
-        dh = ops.gemm(dqkv, wqh, 'nn')
+        dh = ops.gemm(dqkv, wqt, 'nt')
         if lengths is not None:
             ops.mask_rows_(dh, lengths, B, N)
         dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
@@ -198,17 +211,17 @@ class ConvBlockFn(Function):
         coef = ops.brn_finalize(stats, B * N, running_mean, running_std, nbt, brn_w, brn_b, training, BRN_EPS, BRN_MOMENTUM)
         y2 = ops.affine_silu_fwd(hc, coef)
         y = ops.gemm(y2, w2h, 'nt', bias=bpw2, resid=x if residual else None, out_dtype=F32)
-        ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wpw1), wcast_t(wpw2), bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2)
         ctx.cfg = (B, N, training, mode, eps, wpw1.shape, wpw2.shape, wdw.shape, residual)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         B, N, training, mode, eps, w1s, w2s, wdws, residual = ctx.cfg
-        x, nw, nb, mean, rstd, w1h, w2h, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2 = ctx.saved_tensors
+        x, nw, nb, mean, rstd, w1t, w2t, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2 = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
-        dy2 = ops.gemm(dy16, w2h, 'nn')                                               # (M, d)
+        dy2 = ops.gemm(dy16, w2t, 'nt')                                               # (M, d)
         dw2 = _wgrad(dy16, y2, w2s)
         db2 = _bgrad(dy16, bpw2)
         ddw = torch.zeros(wdw2.shape, dtype=F32, device=x.device)
@@ -217,7 +230,7 @@ class ConvBlockFn(Function):
         dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw, dbdw, dbrnw, dbrnb)
         dw1 = _wgrad(dg, h, w1s)
         db1 = _bgrad(dg, bpw1)
-        dh = ops.gemm(dg, w1h, 'nn')
+        dh = ops.gemm(dg, w1t, 'nt')
         dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
         dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
         return (dx, dnw, dnb, dw1, db1, ddw.reshape(wdws), dbdw, dbrnw, dbrnb, None, None, None, dw2, db2) + (None,) * 7
@@ -244,23 +257,23 @@ class SelfCondFn(Function):
         logits = ops.gemm(hn, wfh, 'nt', bias=bff)                                    # (M, V+1) bf16
         p = ops.softmax_fwd(logits, False, BF16)
         y = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32)
-        ctx.save_for_backward(x, nw, nb, mean, rstd, wfh, wrh, bff, bre, hn, p)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wff), wcast_t(wre), bff, bre, hn, p)
         ctx.cfg = (has_norm, mode, eps, wff.shape, wre.shape)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         has_norm, mode, eps, wfs, wrs = ctx.cfg
-        x, nw, nb, mean, rstd, wfh, wrh, bff, bre, hn, p = ctx.saved_tensors
+        x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
-        dp = ops.gemm(dy16, wrh, 'nn')                                                # (M, V+1)
+        dp = ops.gemm(dy16, wrt, 'nt')                                                # (M, V+1)
         dwr = _wgrad(dy16, p, wrs)
         dbr = _bgrad(dy16, bre)
         dl = ops.softmax_bwd(p, dp, False, BF16)
         dwf = _wgrad(dl, hn, wfs)
         dbf = _bgrad(dl, bff)
-        dhn = ops.gemm(dl, wfh, 'nn')
+        dhn = ops.gemm(dl, wft, 'nt')
         if has_norm:
             dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
             dx = ops.norm_bwd(dhn, x, nw, mean, rstd, mode, eps, dy, F32, dnw, dnb)
@@ -292,20 +305,20 @@ class HeadFn(Function):
         wfh = wcast(wff)
         logits = ops.gemm(hn, wfh, 'nt', bias=bff, out_dtype=F32)
         out = logits if return_logits else ops.softmax_fwd(logits, True, F32)
-        ctx.save_for_backward(nw, nb, wfh, bff, hn, out, *saved_norm)
+        ctx.save_for_backward(nw, nb, wcast_t(wff), bff, hn, out, *saved_norm)
         ctx.cfg = (n_norms, mode, eps, return_logits, wff.shape)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         n_norms, mode, eps, return_logits, wfs = ctx.cfg
-        nw, nb, wfh, bff, hn, out = ctx.saved_tensors[:6]
+        nw, nb, wft, bff, hn, out = ctx.saved_tensors[:6]
         sn = ctx.saved_tensors[6:]
         dout = dout.contiguous()
         dl = ops.cast(dout, BF16) if return_logits else ops.softmax_bwd(out, dout, True, BF16)
         dwf = _wgrad(dl, hn, wfs)
         dbf = _bgrad(dl, bff)
-        g = ops.gemm(dl, wfh, 'nn')                                                    # (M,d) bf16
+        g = ops.gemm(dl, wft, 'nt')                                                    # (M,d) bf16
         dnw = torch.zeros_like(nw) if n_norms > 0 else None
         dnb = _zeros_like_param(nb) if n_norms > 0 else None
         for i in reversed(range(n_norms)):
@@ -338,29 +351,29 @@ class SubsampleFn(Function):
         N, F8 = d2.shape[1], d2.shape[2]
         s = ops.sub_silu_transpose(pre2.view(B * N, F8, C))                            # (B*N, C*F8)
         x = ops.gemm(s, woh, 'nt', bias=bout, out_dtype=F32)
-        ctx.save_for_backward(audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s)
+        ctx.save_for_backward(audio, w0f, wd1f, wd2f, wcast_t(wp1), wcast_t(wp2), wcast_t(wout), bp1, bp2, bout, b0, d1, pre1, d2, pre2, s)
         ctx.cfg = (w0.shape, wd1.shape, wp1.shape, wd2.shape, wp2.shape, wout.shape)
         return x.view(B, N, -1)
 
     @staticmethod
     def backward(ctx, dx):
         s0, sd1, sp1, sd2, sp2, so = ctx.cfg
-        audio, w0f, wd1f, wd2f, wp1h, wp2h, woh, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s = ctx.saved_tensors
+        audio, w0f, wd1f, wd2f, wp1t, wp2t, wot, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s = ctx.saved_tensors
         B, N, F8, C = d2.shape
         dev = dx.device
         dx16 = ops.cast(dx.contiguous().view(B * N, -1), BF16)
-        ds = ops.gemm(dx16, woh, 'nn')                                                 # (B*N, C*F8)
+        ds = ops.gemm(dx16, wot, 'nt')                                                 # (B*N, C*F8)
         dwo = _wgrad(dx16, s, so)
         dbo = _bgrad(dx16, bout)
         dpre2 = ops.sub_silu_transpose(pre2.view(B * N, F8, C), ds).view(-1, C)
         dwp2 = _wgrad(dpre2, d2.view(-1, C), sp2)
         dbp2 = _bgrad(dpre2, bp2)
-        dd2 = ops.gemm(dpre2, wp2h, 'nn').view(d2.shape)
+        dd2 = ops.gemm(dpre2, wp2t, 'nt').view(d2.shape)
         dwd2 = torch.zeros(C, 9, dtype=F32, device=dev); dbd2 = torch.zeros(C, dtype=F32, device=dev)
         dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2, dbd2).view(-1, C)
         dwp1 = _wgrad(dpre1, d1.view(-1, C), sp1)
         dbp1 = _bgrad(dpre1, bp1)
-        dd1 = ops.gemm(dpre1, wp1h, 'nn').view(d1.shape)
+        dd1 = ops.gemm(dpre1, wp1t, 'nt').view(d1.shape)
         dwd1 = torch.zeros(C, 9, dtype=F32, device=dev); dbd1 = torch.zeros(C, dtype=F32, device=dev)
         dw0 = torch.zeros(C, 9, dtype=F32, device=dev); db0 = torch.zeros(C, dtype=F32, device=dev)
         ops.sub_stage01_bwd_(dd1, audio, w0f, b0, wd1f, dw0, db0, dwd1, dbd1)          # conv0 recomputed; no (B,T/2,F/2,C) grads

@@ -17,7 +17,7 @@ import torch
 from . import _lib
 
 F32, BF16 = 0, 1
-ACT = {'none': 0, 'gelu': 1, 'silu': 2, 'dgelu': 3, 'dsilu': 4}
+ACT = {'none': 0, 'gelu': 1, 'silu': 2, 'dgelu': 3, 'dsilu': 4, 'gelu_dsave': 5, 'mulaux': 6}
 LAYOUT = {'nt': 0, 'nn': 1, 'tn': 2}
 NORM_MODE = {'layer_norm': 0, 'rms_norm': 1, 'rms_norm_apex': 2}
 
@@ -65,7 +65,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
 
     layout 'nt': a (M,K), b (N,K) — y = x W^T;  'nn': a (M,K), b (K,N) — dx = dy W;  'tn': a (K,M), b (K,N) — dW = dy^T x.
     act 'dgelu'/'dsilu' multiplies by the activation derivative evaluated at aux (M,N) bf16.
-    save_pre returns (C, pre) with pre = A·B + bias in bf16.  split_k > 1 needs out_dtype float32.
+    save_pre returns (C, pre) with pre = A·B + bias in bf16 (act 'gelu_dsave': pre = gelu'(A·B + bias), the factor the
+    backward multiplies by with act 'mulaux').  split_k > 1 needs out_dtype float32.
     """
     _chk(a, 'a', torch.bfloat16); _chk(b, 'b', torch.bfloat16)
     if layout == 'nt':
@@ -157,6 +158,15 @@ def cast(x: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=dtype, device=x.device)
     _lib.call('sconf_cast', _p(x), _dt(x), _p(y), _dt(y), x.numel(), _stream())
     return y
+
+
+def cast_transpose(w: torch.Tensor) -> torch.Tensor:
+    """f32 (R,C) -> bf16 (C,R)."""
+    _chk(w, 'w', torch.float32)
+    R, Cc = w.shape
+    out = torch.empty(Cc, R, dtype=torch.bfloat16, device=w.device)
+    _lib.call('sconf_cast_transpose', _p(w), _p(out), R, Cc, _stream())
+    return out
 
 
 def rotary_qkv_fwd(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], B: int, N: int, H: int, D: int):

@@ -47,7 +47,10 @@ def gemm(a, b, layout='nt', bias=None, resid=None, aux=None, act='none', alpha=1
     else: acc = A.t() @ Bm
     if bias is not None: acc = acc + bias
     pre = acc.to(torch.bfloat16) if save_pre else None
-    if act == 'gelu': acc = _gelu(acc)
+    if act == 'gelu_dsave':
+        pre = _dgelu(acc).to(torch.bfloat16); acc = _gelu(acc)
+    elif act == 'mulaux': acc = acc * aux.to(f32)
+    elif act == 'gelu': acc = _gelu(acc)
     elif act == 'silu': acc = F.silu(acc)
     elif act == 'dgelu': acc = acc * _dgelu(aux.to(f32))
     elif act == 'dsilu': acc = acc * _dsilu(aux.to(f32))
@@ -96,6 +99,9 @@ def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbia
 
 
 def cast(x, dtype): return x.to(dtype)
+
+
+def cast_transpose(w): return w.t().contiguous().to(torch.bfloat16)
 
 
 def _rot(x, cos, sin, sign=1.0):

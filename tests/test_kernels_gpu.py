@@ -51,7 +51,7 @@ def rnd(*shape, dtype=BF, seed=0, scale=1.0):
 
 # ------------------------------------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize('layout', ['nt', 'nn', 'tn'])
-@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 136, 72), (1000, 320, 2560), (64, 64, 8), (513, 256, 300 * 8)])
+@pytest.mark.parametrize('M,N,K', [(128, 128, 64), (200, 144, 72), (1000, 320, 2560), (64, 64, 8), (513, 256, 300 * 8)])
 def test_gemm_plain(ops, layout, M, N, K):
     if layout == 'nt': a, b = rnd(M, K), rnd(N, K, seed=1)
     elif layout == 'nn': a, b = rnd(M, K), rnd(K, N, seed=1)
@@ -84,7 +84,8 @@ def test_gemm_epilogues(ops, layout):
     bias = rnd(N, dtype=F32, seed=2)
     resid = rnd(M, N, dtype=F32, seed=3)
     aux = rnd(M, N, seed=4)
-    for kw in (dict(bias=bias), dict(bias=bias, act='gelu', save_pre=True), dict(act='silu'),
+    for kw in (dict(bias=bias), dict(bias=bias, act='gelu', save_pre=True), dict(bias=bias, act='gelu_dsave', save_pre=True),
+               dict(aux=aux, act='mulaux', alpha=0.5), dict(act='silu'),
                dict(aux=aux, act='dgelu', alpha=0.5), dict(aux=aux, act='dsilu'),
                dict(bias=bias, resid=resid, alpha=0.5, out_dtype=F32), dict(resid=resid, out_dtype=F32)):
         kd = {k: dev(v) for k, v in kw.items()}
