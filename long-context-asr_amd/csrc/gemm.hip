@@ -17,39 +17,17 @@
 // is conflict-free.  The MFMA is issued with the operands swapped (acc = B·A^T) so that each lane
 // owns 4 *consecutive output columns* of one row: bias/residual/aux traffic and the C store are
 // 8-16 B per lane.  Block ids are remapped so that consecutive tiles stay on one XCD (shared L2).
-#include "common.h"
+#include "gemm_tile.h"
 #include <stdlib.h>
 #include <algorithm>
 
 SCONF_API int sconf_num_cus(void);
 
 namespace {
+using namespace gemm_tile;
 
 constexpr int BM = 128, BN = 128, BK = 64;
 constexpr int TILE_BYTES = 128 * 64 * 2;          // 16 KiB per operand tile
-
-struct GemmParams {
-    const bf16* A; const bf16* B; void* C;
-    int M, N, K;
-    long lda, ldb, ldc;
-    const float* bias;                              // [N] or null
-    const float* resid; long ldr;                   // f32 [M][ldr] or null  (out = resid + alpha*val)
-    const bf16* aux; long ldaux;                    // bf16 [M][ldaux] for DGELU / DSILU
-    bf16* pre; long ldpre;                          // optional pre-activation save (acc + bias)
-    float alpha;
-    int act;                                        // SconfAct
-    int out_f32;                                    // 1: C is float, 0: C is bf16
-    long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
-    int k_per_split;                                // multiple of BK
-    int splits;
-};
-
-__device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
-// XOR swizzle (in 16-B chunks) of a K-contiguous tile row.  The A image is read 16 consecutive rows at a time; the B
-// image is read with the PERMUTED row set {16p + 4j + e} (see tile_mma), so it needs a different conflict-free function.
-template <bool BIMG> __device__ __forceinline__ int swz_kc(int row) {
-    return BIMG ? (((row >> 1) & 1) | (((row >> 4) & 3) << 1)) : ((row >> 1) & 7);
-}
 
 // ---- global -> register staging of one 128 x 64 operand tile (4 x 16 B per thread) ----------
 template <bool KS>
@@ -150,122 +128,17 @@ __device__ __forceinline__ bf16x8 frag_read(const char* s, int rbase, int j, int
     }
 }
 
-// ---- narrow epilogue (K-strided B: NN / TN): lane owns row m and 4 consecutive columns of each 16x16 tile --------------
+// ---- epilogues of the 64x64 wave tile: four 16-row blocks, each handled by the shared row-block routines ----------------
 __device__ __forceinline__ void gemm_epilogue_narrow(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
     const int nb = n0 + wn * 64 + (lane >> 4) * 4;
-    const bool dact = p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
+    const int ncol[4] = {nb, nb + 16, nb + 32, nb + 48};
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        bf16x4 ax[4];
-        float4 rs[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                          // phase 1: loads
-            const int n = nb + j * 16;
-            ax[j] = bf16x4{(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-            rs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < p.N) {
-                if (dact) ax[j] = *reinterpret_cast<const bf16x4*>(p.aux + (long)m * p.ldaux + n);
-                if (p.resid) rs[j] = *reinterpret_cast<const float4*>(p.resid + (long)m * p.ldr + n);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {                          // phase 2: math + stores
-            const int n = nb + j * 16;
-            if (n >= p.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (p.bias) {
-                float bs[4]; load4(p.bias + n, bs);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] += bs[e];
-            }
-            if (p.act == SCONF_ACT_GELU_DSAVE) {
-                float dg[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) gelu_both(v[e], v[e], dg[e]);
-                store4(p.pre + (long)m * p.ldpre + n, dg);
-            } else if (p.pre) store4(p.pre + (long)m * p.ldpre + n, v);
-            if (p.act == SCONF_ACT_MULAUX) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= (float)ax[j][e];
-            } else if (p.act == SCONF_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = geluf_(v[e]);
-            } else if (p.act == SCONF_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = siluf_(v[e]);
-            } else if (dact) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] *= (p.act == SCONF_ACT_DGELU ? dgeluf_((float)ax[j][e]) : dsiluf_((float)ax[j][e]));
-            }
-            const float r[4] = {rs[j].x, rs[j].y, rs[j].z, rs[j].w};
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = v[e] * p.alpha + r[e];
-            if (p.out_f32) store4(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
-            else           store4(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
-        }
-    }
+    for (int i = 0; i < 4; ++i) epi_narrow_row(p, acc[i], m0 + wm * 64 + i * 16 + (lane & 15), ncol, split);
 }
-
-// ---- epilogue: lane (r = lane&15, g = lane>>4) owns, for each row block i, row m = .. + 16i + r and the 16 consecutive
-// columns n = n0 + 64*wn + 16*g + (0..15): acc[i][j][e] is column 4j + e of that run.  All loads of a row block
-// (aux / residual) are issued before its math and stores.
 __device__ __forceinline__ void gemm_epilogue(const GemmParams& p, const f32x4 (&acc)[4][4], int m0, int n0, int split, int wm, int wn, int lane) {
     const int nrun = n0 + wn * 64 + (lane >> 4) * 16;
-    if (nrun >= p.N) return;                                // N % 16 == 0 (host-checked): the 16-column run is all-in or all-out
-    const bool dact = p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        // the run is handled as two 8-column halves (16 B of bf16 / 32 B of f32 per lane each) to bound live registers;
-        // both halves' loads are issued first
-        float ax[2][8], rs[2][8];
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            if (dact) load8(p.aux + (long)m * p.ldaux + nrun + 8 * hh, ax[hh]);
-            if (p.resid) load8(p.resid + (long)m * p.ldr + nrun + 8 * hh, rs[hh]);
-        }
-#pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-            const int n = nrun + 8 * hh;
-            float v[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * hh + (e >> 2)][e & 3];
-            if (p.bias) {
-                float bs[8]; load8(p.bias + n, bs);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += bs[e];
-            }
-            if (p.act == SCONF_ACT_GELU_DSAVE) {
-                float dg[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) gelu_both(v[e], v[e], dg[e]);
-                store8(p.pre + (long)m * p.ldpre + n, dg);
-            } else if (p.pre) store8(p.pre + (long)m * p.ldpre + n, v);
-            if (p.act == SCONF_ACT_MULAUX) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= ax[hh][e];
-            } else if (p.act == SCONF_ACT_GELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = geluf_(v[e]);
-            } else if (p.act == SCONF_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = siluf_(v[e]);
-            } else if (p.act == SCONF_ACT_DGELU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dgeluf_(ax[hh][e]);
-            } else if (p.act == SCONF_ACT_DSILU) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] *= dsiluf_(ax[hh][e]);
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] * p.alpha + (p.resid ? rs[hh][e] : 0.f);
-            if (p.out_f32) store8(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
-            else           store8(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
-        }
-    }
+    for (int i = 0; i < 4; ++i) epi_wide_row(p, acc[i], m0 + wm * 64 + i * 16 + (lane & 15), nrun, split);
 }
 
 // Work item v in [0, ntiles * splits) -> (m0, n0, K range).
@@ -456,6 +329,9 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.splits = splits;
     p.split_stride = splits > 1 ? M * ldc : 0;
     if (splits > 1) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
+
+    // A/B switch (read per call so that one process can compare both kernels): keep everything on the 128x128 kernel
+    if (!getenv("SCONF_GEMM_NO_256") && sconf_gemm256_eligible(p, layout)) return sconf_gemm256_launch(p, layout, stream);
 
     const int ntiles = cdiv(M, BM) * cdiv(N, BN);
     dim3 grid(ntiles * splits), block(256);

@@ -1,0 +1,376 @@
+// bf16 MFMA GEMM, 256x256x64 block tile, 8 waves, for the large projections of the SConformerXL path (same contract and
+// epilogues as gemm.hip; chosen by sconf_gemm_bf16 when M and N are multiples of 256 and K of 64).
+//
+// Why a second kernel: a 128x128 tile moves 2 x 128 x 64 x 2 B = 32 KiB through the CU's 64 B/clk vector-memory path
+// for 2 x 128 x 128 x 64 flop, i.e. exactly the time the four SIMDs need for the MFMAs: the load path and the matrix
+// cores are co-critical and any stall shows.  A 256x256 tile halves the bytes per flop, and a 128x64 wave tile cuts the
+// LDS fragment reads per MFMA from 0.5 to 0.375.
+//
+// Structure (one workgroup per CU, 128 KiB LDS = 2 K-tile buffers x {A0, A1, B0, B1} half-tile images of 128 x 64):
+//  * waves 2 (M) x 4 (N); a wave owns rows {64wr..+63} of BOTH A halves and 32 + 32 columns from the two B halves, so
+//    each half-tile image is read in exactly one of the four phases of a K-tile and can be restaged right after it;
+//  * a K-tile is 4 phases (one 64 x 32 quadrant of the wave tile each): { fragment ds_reads, one half-tile of LDS-DMA
+//    prefetch, counted s_waitcnt vmcnt } -> s_barrier -> 16 MFMA -> s_barrier.  The DMA stream runs 5 phases ahead of
+//    its consumer and is never drained inside the loop (raw s_barrier, never __syncthreads);
+//  * the two wave rows run one barrier apart (wr = 1 executes one extra s_barrier per work item), so that while one
+//    half of the waves is in its MFMA cluster the other half issues its LDS reads and DMA;
+//  * persistent workgroups walk (K-split, tile) work items; the prefetch cursor crosses item boundaries, so an item's
+//    epilogue stores overlap the next item's first loads.
+//
+// Hazards, by construction (phase P = 4 * k_tile + q; both wave rows issue their share of a half-tile in their own L_P):
+//   WAR  an image read in L_P is restaged in L_(P+2) at the earliest: every reader has passed the lgkmcnt(0) that
+//        precedes its MFMAs of phase P, and two barriers lie in between even for the lagging wave row;
+//   RAW  the wait at the end of L_P leaves the 4 youngest half-tiles (8 DMA instructions per wave) in flight, so every
+//        half-tile issued in phases <= P-4 has landed for the issuing wave; the barrier that ends L_P (L_P of the lagging
+//        row included) makes that true for all waves before any L_(P+1) read.  Issue phases: A0, B0 of K-tile s+2 in
+//        (s, q2), (s, q3); B1, A1 of K-tile s+1 in (s, q0), (s, q1); read phases: A0/B0 q0, B1 q1, A1 q2 - always >= 5
+//        phases after the issue.
+#include "gemm_tile.h"
+#include <algorithm>
+#include <stdlib.h>
+
+SCONF_API int sconf_num_cus(void);
+
+namespace {
+using namespace gemm_tile;
+
+// Tile = 256 rows x (128 + 64 * JH) columns: JH = 2 -> 256x256; JH = 1 -> 256x192 (NT only), which turns the 384 tiles of
+// an N = 768 projection (1.5 rounds over 256 CUs) into 512 (exactly 2 rounds).
+constexpr int TM = 256, TK = 64;
+constexpr int HT = 128 * 64 * 2;                   // one half-tile image, 16 KiB (B1 of the 192-wide tile uses half of it)
+constexpr int BUF = 4 * HT;                        // A0 | A1 | B0 | B1
+constexpr int GM2 = 4;                             // row panels per L2 patch (4 x 8 tiles = the 32 workgroups of one XCD)
+
+typedef const __attribute__((address_space(1))) void* gptr;
+typedef __attribute__((address_space(3))) void* lptr;
+typedef __attribute__((address_space(3))) bf16x4* lds_p4;
+
+// K-contiguous images are [rows][64 k] with a 16-B-chunk XOR swizzle per row.
+// A image: the half's 128 rows in natural order, read 16 consecutive rows at a time.
+// B images: a wave owns WC = 32 + 16 * JH tile columns, WC * wc + (0 .. WC-1): the first 32 live in B0 (row 32wc + c), the
+//   rest in B1 (row 16 JH wc + c - 32).  A wave reads the PERMUTED row set  base + 8 * (a >> 2) + 4j + (a & 3)  (a = lane & 15;
+//   B1 of the 192-wide tile: base + 4 * (a >> 2) + (a & 3)) for column tile j, so that with the MFMA issued operand-swapped
+//   lane (r, g) accumulates the 8 consecutive columns 8g .. 8g+7 of the wave's B0 part (and 8 or 4 of its B1 part): each
+//   epilogue store instruction then writes 64 contiguous bytes per row.
+__device__ __forceinline__ int swz_a(int row) { return (row >> 1) & 7; }
+__device__ __forceinline__ int swz_b(int row) { return ((row >> 1) & 1) | (((row >> 3) & 3) << 1); }
+__device__ __forceinline__ int swz_b1n(int row) { return ((row >> 1) & 1) | (((row >> 2) & 3) << 1); }   // 64-row B1 image
+
+// per-lane source byte offsets (relative to the half-tile's wave-uniform base) of the DMA pieces of each half
+template <bool KS, bool BOP, int JH> struct DmaOffs {
+    unsigned off[2][2];
+    __device__ __forceinline__ void set(long ld, int tid) {
+        constexpr int WC = 32 + 16 * JH;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int c = tid + 512 * i;
+                if (!KS) {
+                    const int row = c >> 3, pos = c & 7;
+                    int kc, mrow;
+                    if (!BOP)              { kc = pos ^ swz_a(row); mrow = 128 * h + row; }
+                    else if (h == 0)       { kc = pos ^ swz_b(row); mrow = WC * (row >> 5) + (row & 31); }
+                    else if (JH == 2)      { kc = pos ^ swz_b(row); mrow = WC * (row >> 5) + 32 + (row & 31); }
+                    else                   { kc = pos ^ swz_b1n(row & 63); mrow = WC * ((row & 63) >> 4) + 32 + (row & 15); }
+                    off[h][i] = (unsigned)(((long)mrow * ld + kc * 8) * 2);
+                } else {
+                    const int kr = c >> 4, pos = c & 15, rc = pos ^ swz_strided(kr);
+                    off[h][i] = (unsigned)(((long)kr * ld + 128 * h + rc * 8) * 2);
+                }
+            }
+    }
+};
+template <int NP>
+__device__ __forceinline__ void dma_half(const char* base, const unsigned (&off)[2], char* dst, int tid) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i)
+        __builtin_amdgcn_global_load_lds((gptr)(base + off[i]), (lptr)(dst + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
+}
+
+// 16 x 32 MFMA fragments.  K-contiguous: one ds_read_b128; K-strided ([64 k][128 cols] image): two transposed reads.
+template <bool KS> __device__ __forceinline__ bf16x8 frag_a(const char* s, int wr, int i, int kk, int lane) {
+    if (!KS) {
+        const int r = 64 * wr + 16 * i + (lane & 15), c = kk * 4 + (lane >> 4);
+        return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ swz_a(r)) << 4));
+    } else {
+        const int a = lane & 15, q = a >> 2, pp = a & 3, g = lane >> 4;
+        const int col = 64 * wr + 16 * i + 4 * pp, chunk = col >> 3, sub = (col & 4) * 2;
+        const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+template <bool KS, bool NARROW> __device__ __forceinline__ bf16x8 frag_b(const char* s, int wc, int j, int kk, int lane) {
+    if (!KS) {
+        const int a = lane & 15, c = kk * 4 + (lane >> 4);
+        if (!NARROW) {
+            const int r = 32 * wc + 8 * (a >> 2) + 4 * j + (a & 3);
+            return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ swz_b(r)) << 4));
+        } else {
+            const int r = 16 * wc + 4 * (a >> 2) + (a & 3);
+            return *reinterpret_cast<const bf16x8*>(s + r * 128 + ((c ^ swz_b1n(r)) << 4));
+        }
+    } else {
+        const int a = lane & 15, q = a >> 2, pp = a & 3, g = lane >> 4;
+        const int col = 32 * wc + 16 * j + 4 * pp, chunk = col >> 3, sub = (col & 4) * 2;
+        const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
+        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub));
+        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub));
+        return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+}
+
+// Work items (K-split, 256x256 tile): XCD-contiguous ids, split-major, GM2 x tiles_n patches (see gemm.hip tile_coords).
+struct Item { int m0, n0, kbeg, nkt, split; };
+struct Sched { int total, ntiles, tiles_m, tiles_n, tn; };
+__device__ __forceinline__ Item item_coords(const GemmParams& p, const Sched& sc, int v) {
+    const int qx = sc.total >> 3, rx = sc.total & 7, xcd = v & 7;
+    const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (v >> 3);
+    const int split = lid / sc.ntiles, t = lid - split * sc.ntiles;
+    const int per_group = GM2 * sc.tiles_n;
+    const int g = t / per_group, r = t - g * per_group;
+    const int first_m = g * GM2, gm = min(GM2, sc.tiles_m - first_m);
+    Item w;
+    w.m0 = (first_m + r % gm) * TM; w.n0 = (r / gm) * sc.tn;
+    w.split = split;
+    w.kbeg = split * p.k_per_split;
+    w.nkt = (min(p.K, w.kbeg + p.k_per_split) - w.kbeg) / TK;
+    return w;
+}
+// position in the workgroup's stream of K-tiles (all wave-uniform)
+struct Cursor {
+    int v, kt, par; bool valid; Item it;
+    __device__ __forceinline__ void advance(const GemmParams& p, const Sched& sc) {
+        par ^= 1;
+        if (++kt < it.nkt) return;
+        kt = 0; v += gridDim.x;
+        if (v < sc.total) it = item_coords(p, sc, v); else valid = false;
+    }
+};
+
+#define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// leave the 4 youngest half-tiles in flight: 2 + 2 + 2 + JH DMA instructions per wave
+template <int JH> __device__ __forceinline__ void wait_window(bool streaming) {
+    if (!streaming) VMCNT(0);
+    else if (JH == 2) VMCNT(8);
+    else VMCNT(7);
+}
+
+template <bool KS, int JH>
+__global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
+    constexpr int WC = 32 + 16 * JH, TN = 4 * WC;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A0 | A1 | B0 | B1], 128 KiB: the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    Sched sc;
+    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits;
+    if ((int)blockIdx.x >= sc.total) return;
+
+    DmaOffs<KS, false, JH> oa; DmaOffs<KS, true, JH> ob;
+    oa.set(p.lda, tid); ob.set(p.ldb, tid);
+    auto issue_a = [&](const Cursor& c, int h) {
+        if (!c.valid) return;
+        const long k0 = c.it.kbeg + c.kt * TK;
+        const char* base = reinterpret_cast<const char*>(p.A) + (KS ? k0 * p.lda + c.it.m0 : (long)c.it.m0 * p.lda + k0) * 2;
+        dma_half<2>(base, oa.off[h], smem + c.par * BUF + h * HT, tid);
+    };
+    auto issue_b = [&](const Cursor& c, int h) {
+        if (!c.valid) return;
+        const long k0 = c.it.kbeg + c.kt * TK;
+        const char* base = reinterpret_cast<const char*>(p.B) + (KS ? k0 * p.ldb + c.it.n0 : (long)c.it.n0 * p.ldb + k0) * 2;
+        if (h == 0) dma_half<2>(base, ob.off[0], smem + c.par * BUF + 2 * HT, tid);
+        else        dma_half<JH>(base, ob.off[1], smem + c.par * BUF + 3 * HT, tid);
+    };
+
+    f32x4 acc[2][4][2 + JH];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2 + JH; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Cursor pc;                                        // prefetch cursor
+    pc.v = blockIdx.x; pc.kt = 0; pc.par = 0; pc.valid = true; pc.it = item_coords(p, sc, pc.v);
+    int cv = pc.v; Item cit = pc.it;                  // compute position
+    // prologue: K-tile 0 entirely, A0/B0 of K-tile 1 (the "phases -6 .. -1" of the schedule)
+    issue_a(pc, 0); issue_b(pc, 0); issue_b(pc, 1); issue_a(pc, 1);
+    pc.advance(p, sc);
+    issue_a(pc, 0); issue_b(pc, 0);
+    if (pc.valid) wait_window<JH>(true);             // A0, B0 of K-tile 0 have landed
+    else if (JH == 2) VMCNT(4); else VMCNT(3);
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    bf16x8 fa[4][2], blo[2][2], bhi[JH][2];
+    while (true) {
+        if (wr) __builtin_amdgcn_s_barrier();         // stagger the second wave row by one barrier
+        for (int kt = 0; kt < cit.nkt; ++kt) {
+            const char* buf = smem + cur * BUF;
+            const bool last = kt == cit.nkt - 1;
+            // ---- q0: B-lo, A-lo -> acc[0][.][0..1] ---------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) blo[j][kk] = frag_b<KS, false>(buf + 2 * HT, wc, j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf, wr, i, kk, lane);
+            issue_b(pc, 1);
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], fa[i][kk], acc[0][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- q1: B-hi -> acc[0][.][2..3] ---------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < JH; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) bhi[j][kk] = frag_b<KS, JH == 1>(buf + 3 * HT, wc, j, kk, lane);
+            issue_a(pc, 1);
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < JH; ++j)
+                        acc[0][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[j][kk], fa[i][kk], acc[0][i][2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- q2: A-hi -> acc[1][.][2..3] ---------------------------------------------------------------------
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf + HT, wr, i, kk, lane);
+            pc.advance(p, sc);
+            issue_a(pc, 0);
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < JH; ++j)
+                        acc[1][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[j][kk], fa[i][kk], acc[1][i][2 + j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- q3: (B-lo still in registers) -> acc[1][.][0..1] ------------------------------------------------
+            issue_b(pc, 0);
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], fa[i][kk], acc[1][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (!(wr && last)) __builtin_amdgcn_s_barrier();   // the lagging row goes straight into its epilogue
+            cur ^= 1;
+        }
+        // ---- epilogue: both wave rows concurrently --------------------------------------------------------------------
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = cit.m0 + 128 * h + 64 * wr + 16 * i + (lane & 15);
+                if constexpr (!KS) {
+                    const int g = lane >> 4, nlo = cit.n0 + WC * wc + 8 * g, nhi = cit.n0 + WC * wc + 32 + 4 * JH * g;
+                    EpiIn<8> ilo; EpiIn<4 * JH> ihi;
+                    epi_load<8>(p, ilo, m, nlo); epi_load<4 * JH>(p, ihi, m, nhi);
+                    float vlo[8], vhi[4 * JH];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vlo[e] = acc[h][i][e >> 2][e & 3];
+#pragma unroll
+                    for (int e = 0; e < 4 * JH; ++e) vhi[e] = acc[h][i][2 + (e >> 2)][e & 3];
+                    epi_apply<8>(p, vlo, ilo, m, nlo, cit.split);
+                    epi_apply<4 * JH>(p, vhi, ihi, m, nhi, cit.split);
+                } else {
+                    const int nb = cit.n0 + 32 * wc + 4 * (lane >> 4);
+                    const int ncol[4] = {nb, nb + 16, nb + 128, nb + 144};
+                    epi_narrow_row(p, acc[h][i], m, ncol, cit.split);
+                }
+#pragma unroll
+                for (int j = 0; j < 2 + JH; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        __builtin_amdgcn_s_barrier();                 // re-align the two wave rows
+        cv += gridDim.x;
+        if (cv >= sc.total) break;
+        cit = item_coords(p, sc, cv);
+    }
+    VMCNT(0);
+}
+
+}  // namespace
+
+// Tile width for the NT layout: fewest "rounds x width" over the CUs (ties -> the wider tile); 0 = not eligible.
+static int pick_width(const GemmParams& p, int layout, int cus) {
+    if (p.M % TM || p.K % TK || p.k_per_split % TK) return 0;
+    if (const char* e = getenv("SCONF_GEMM_256_WIDTH")) {                 // benchmarking override
+        const int w = atoi(e);
+        return ((w == 256 || (w == 192 && layout == 0)) && p.N % w == 0) ? w : 0;
+    }
+    long best = 0; int bw = 0;
+    for (int w : {256, 192}) {
+        if (p.N % w || (w == 192 && layout != 0)) continue;
+        const long items = (long)(p.M / TM) * (p.N / w) * p.splits;
+        const long cost = ((items + cus - 1) / cus) * w * (w == 192 ? 9 : 8);   // the 192-wide tile runs ~12 % below the 256 one per flop
+        if (!bw || cost < best) { best = cost; bw = w; }
+    }
+    return bw;
+}
+static int num_cus_cached() {
+    static int cus = 0;
+    if (!cus) { const int n = sconf_num_cus(); cus = n > 0 ? n : 256; }
+    return cus;
+}
+
+bool sconf_gemm256_eligible(const GemmParams& p, int layout) {
+    if (layout != 0 && layout != 2) return false;
+    const bool ks = layout == 2;
+    // 32-bit per-lane source offsets relative to a half-tile base
+    if ((ks ? 64 : 256) * p.lda * 2 >= (1L << 32) || (ks ? 64 : 256) * p.ldb * 2 >= (1L << 32)) return false;
+    const int cus = num_cus_cached();
+    const int w = pick_width(p, layout, cus);
+    if (!w) return false;
+    // one workgroup per CU: below ~3/4 of a round the 128x128 kernel (2 per CU, 4x the tiles) fills the chip better
+    return (long)(p.M / TM) * (p.N / w) * p.splits * 4 >= 3L * cus;
+}
+
+int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
+    static bool attr_set = false;
+    const size_t shmem = 2 * BUF;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        attr_set = true;
+    }
+    const int cus = num_cus_cached();
+    const int w = pick_width(p, layout, cus);
+    const int total = (p.M / TM) * (p.N / w) * p.splits;
+    dim3 grid(std::min(total, cus)), block(512);
+    if (layout == 2)   hipLaunchKernelGGL((gemm256_kernel<true, 2>), grid, block, shmem, stream, p);
+    else if (w == 256) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, shmem, stream, p);
+    else               hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);
+    SCONF_LAUNCH_OK("sconf_gemm_bf16 (256-row tile)");
+    return 0;
+}

@@ -1,0 +1,118 @@
+// Pieces shared by the bf16 GEMM kernels (gemm.hip: 128x128 tile / 4 waves; gemm256.hip: 256x256 tile / 8 waves):
+// the launch parameter block, the LDS swizzles and the fused epilogues, written per 16-row block of one wave.
+#pragma once
+#include "common.h"
+
+namespace gemm_tile {
+
+struct GemmParams {
+    const bf16* A; const bf16* B; void* C;
+    int M, N, K;
+    long lda, ldb, ldc;
+    const float* bias;                              // [N] or null
+    const float* resid; long ldr;                   // f32 [M][ldr] or null  (out = resid + alpha*val)
+    const bf16* aux; long ldaux;                    // bf16 [M][ldaux] for DGELU / DSILU
+    bf16* pre; long ldpre;                          // optional pre-activation save (acc + bias)
+    float alpha;
+    int act;                                        // SconfAct
+    int out_f32;                                    // 1: C is float, 0: C is bf16
+    long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
+    int k_per_split;                                // multiple of BK
+    int splits;
+};
+
+__device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
+// XOR swizzle (in 16-B chunks) of a K-contiguous tile row.  The A image is read 16 consecutive rows at a time; the B
+// image is read with the PERMUTED row set {16p + 4j + e} (see tile_mma), so it needs a different conflict-free function.
+template <bool BIMG> __device__ __forceinline__ int swz_kc(int row) {
+    return BIMG ? (((row >> 1) & 1) | (((row >> 4) & 3) << 1)) : ((row >> 1) & 7);
+}
+
+
+// ---- fused epilogue, per run of W (4 or 8) consecutive output columns of one row ---------------------------------------------
+//   out = resid + alpha * act(acc + bias)        (act may also save gelu' / the pre-activation, or multiply by aux)
+// Split in two steps so that a caller can issue the aux / residual loads of all its runs before any math or store.
+template <int W> __device__ __forceinline__ void loadv(const bf16* p, float (&v)[W]) { if constexpr (W == 8) load8(p, v); else load4(p, v); }
+template <int W> __device__ __forceinline__ void loadv(const float* p, float (&v)[W]) { if constexpr (W == 8) load8(p, v); else load4(p, v); }
+template <int W> __device__ __forceinline__ void storev(bf16* p, const float (&v)[W]) { if constexpr (W == 8) store8(p, v); else store4(p, v); }
+template <int W> __device__ __forceinline__ void storev(float* p, const float (&v)[W]) { if constexpr (W == 8) store8(p, v); else store4(p, v); }
+
+template <int W> struct EpiIn { float ax[W], rs[W]; };
+__device__ __forceinline__ bool epi_uses_aux(const GemmParams& p) {
+    return p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
+}
+template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, EpiIn<W>& in, int m, int n) {
+#pragma unroll
+    for (int e = 0; e < W; ++e) { in.ax[e] = 0.f; in.rs[e] = 0.f; }
+    if (epi_uses_aux(p)) loadv<W>(p.aux + (long)m * p.ldaux + n, in.ax);
+    if (p.resid) loadv<W>(p.resid + (long)m * p.ldr + n, in.rs);
+}
+template <int W> __device__ __forceinline__ void epi_apply(const GemmParams& p, float (&v)[W], const EpiIn<W>& in, int m, int n, int split) {
+    if (p.bias) {
+        float bs[W]; loadv<W>(p.bias + n, bs);
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] += bs[e];
+    }
+    if (p.act == SCONF_ACT_GELU_DSAVE) {
+        float dg[W];
+#pragma unroll
+        for (int e = 0; e < W; ++e) gelu_both(v[e], v[e], dg[e]);
+        storev<W>(p.pre + (long)m * p.ldpre + n, dg);
+    } else if (p.pre) storev<W>(p.pre + (long)m * p.ldpre + n, v);
+    if (p.act == SCONF_ACT_MULAUX) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] *= in.ax[e];
+    } else if (p.act == SCONF_ACT_GELU) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = geluf_(v[e]);
+    } else if (p.act == SCONF_ACT_SILU) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = siluf_(v[e]);
+    } else if (p.act == SCONF_ACT_DGELU) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] *= dgeluf_(in.ax[e]);
+    } else if (p.act == SCONF_ACT_DSILU) {
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] *= dsiluf_(in.ax[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + in.rs[e];
+    if (p.out_f32) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
+    else           storev<W>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
+}
+
+// narrow row block (K-strided B: NN / TN): lane (r = lane&15, g = lane>>4) owns row m and, in each of four 16-column tiles
+// j, the 4 consecutive columns ncol[j] .. +3 (ncol[j] already includes the lane's 4*g)
+__device__ __forceinline__ void epi_narrow_row(const GemmParams& p, const f32x4 (&acc)[4], int m, const int (&ncol)[4], int split) {
+    if (m >= p.M) return;
+    EpiIn<4> in[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (ncol[j] < p.N) epi_load<4>(p, in[j], m, ncol[j]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (ncol[j] >= p.N) continue;
+        float v[4] = {acc[j][0], acc[j][1], acc[j][2], acc[j][3]};
+        epi_apply<4>(p, v, in[j], m, ncol[j], split);
+    }
+}
+// wide row block (NT): the lane owns row m and the 16 consecutive columns nrun .. nrun+15 (acc[j][e] = column 4j + e),
+// handled as two 8-column runs (16 B of bf16 / 32 B of f32 per lane each)
+__device__ __forceinline__ void epi_wide_row(const GemmParams& p, const f32x4 (&acc)[4], int m, int nrun, int split) {
+    if (m >= p.M || nrun >= p.N) return;                  // N % 16 == 0 (host-checked): the run is all-in or all-out
+    EpiIn<8> in[2];
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) epi_load<8>(p, in[hh], m, nrun + 8 * hh);
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[2 * hh + (e >> 2)][e & 3];
+        epi_apply<8>(p, v, in[hh], m, nrun + 8 * hh, split);
+    }
+}
+
+}  // namespace gemm_tile
+
+// 256x256-tile kernel (gemm256.hip).  Returns false when the problem does not meet its shape requirements.
+bool sconf_gemm256_eligible(const gemm_tile::GemmParams& p, int layout);
+int  sconf_gemm256_launch(const gemm_tile::GemmParams& p, int layout, hipStream_t stream);

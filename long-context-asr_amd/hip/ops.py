@@ -105,8 +105,14 @@ def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
 
     The GEMM runs at most 2 persistent workgroups per CU (`slots`) that walk the tiles x s work items, each item being
     ceil(nkt / s) K-steps plus an epilogue of f32 atomics worth ~3 K-steps.  Pick the s that minimises the critical path."""
-    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     nkt = (K + 63) // 64
+    if M % 256 == 0 and N % 256 == 0 and K % 64 == 0:
+        # 256x256-tile kernel (gemm256.hip): one workgroup per CU, so aim at one full round of (tile, split) items; with
+        # very few tiles the per-split slabs get too many and the 128x128 kernel below does better
+        tiles256 = (M // 256) * (N // 256)
+        if 16 <= tiles256 <= n_cus and nkt >= 32:
+            return max(1, min(n_cus // tiles256, nkt // 8))
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
     slots = 2 * n_cus
     if tiles >= slots or nkt < 32:
         return 1
