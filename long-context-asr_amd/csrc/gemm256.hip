@@ -150,6 +150,87 @@ struct Cursor {
     }
 };
 
+// Epilogue of one work item for one wave (ACT and the presence of a residual fixed at compile time).  All loads are issued
+// before the stores they could queue behind: the bias run once, the aux tile (bf16) per half of 4 row blocks, the residual
+// (f32) per pair of row blocks - as far ahead as the 256-VGPR budget beside the 128 accumulator registers allows.
+template <int W> struct RawBf;
+template <> struct RawBf<8> { typedef bf16x8 type; };
+template <> struct RawBf<4> { typedef bf16x4 type; };
+template <int ACT, bool RES, bool KS, int JH>
+__device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[2][4][2 + JH], const Item& it, int wr, int wc, int lane) {
+    constexpr int WC = 32 + 16 * JH, WH = 4 * JH;
+    constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX;
+    const int g = lane >> 4, mbase = it.m0 + 64 * wr + (lane & 15);
+    if constexpr (!KS) {
+        const int nlo = it.n0 + WC * wc + 8 * g, nhi = it.n0 + WC * wc + 32 + WH * g;
+        float blo[8], bhi[WH];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) blo[e] = 0.f;
+#pragma unroll
+        for (int e = 0; e < WH; ++e) bhi[e] = 0.f;
+        if (p.bias) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            typename RawBf<8>::type axlo[4];
+            typename RawBf<WH>::type axhi[4];
+            if constexpr (AUX) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16* q = p.aux + (long)(mbase + 128 * h + 16 * i) * p.ldaux;
+                    axlo[i] = *reinterpret_cast<const typename RawBf<8>::type*>(q + nlo);
+                    axhi[i] = *reinterpret_cast<const typename RawBf<WH>::type*>(q + nhi);
+                }
+            }
+#pragma unroll
+            for (int i2 = 0; i2 < 4; i2 += 2) {
+                float rlo[2][8], rhi[2][WH];
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) rlo[ii][e] = 0.f;
+#pragma unroll
+                    for (int e = 0; e < WH; ++e) rhi[ii][e] = 0.f;
+                    if constexpr (RES) {
+                        const float* q = p.resid + (long)(mbase + 128 * h + 16 * (i2 + ii)) * p.ldr;
+                        loadv<8>(q + nlo, rlo[ii]); loadv<WH>(q + nhi, rhi[ii]);
+                    }
+                }
+#pragma unroll
+                for (int ii = 0; ii < 2; ++ii) {
+                    const int i = i2 + ii, m = mbase + 128 * h + 16 * i;
+                    float vlo[8], vhi[WH], alo[8], ahi[WH];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)axlo[i][e] : 0.f; }
+#pragma unroll
+                    for (int e = 0; e < WH; ++e) { vhi[e] = acc[h][i][2 + (e >> 2)][e & 3]; ahi[e] = AUX ? (float)axhi[i][e] : 0.f; }
+                    epi_math_store<8, ACT>(p, vlo, blo, alo, rlo[ii], m, nlo, it.split);
+                    epi_math_store<WH, ACT>(p, vhi, bhi, ahi, rhi[ii], m, nhi, it.split);
+                }
+            }
+        }
+    } else {
+        // K-strided operands keep natural column order: 4 consecutive columns per lane and 16x16 tile (plain epilogue only)
+        const int nb = it.n0 + 32 * wc + 4 * g;
+        const int ncol[4] = {nb, nb + 16, nb + 128, nb + 144};
+        float zero[4] = {0.f, 0.f, 0.f, 0.f}, bs[4][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bs[j][e] = 0.f;
+            if (p.bias) loadv<4>(p.bias + ncol[j], bs[j]);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float v[4] = {acc[h][i][j][0], acc[h][i][j][1], acc[h][i][j][2], acc[h][i][j][3]};
+                    epi_math_store<4, ACT>(p, v, bs[j], zero, zero, mbase + 128 * h + 16 * i, ncol[j], it.split);
+                }
+    }
+}
+
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // leave the 4 youngest half-tiles in flight: 2 + 2 + 2 + JH DMA instructions per wave
 template <int JH> __device__ __forceinline__ void wait_window(bool streaming) {
@@ -286,31 +367,20 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             if (!(wr && last)) __builtin_amdgcn_s_barrier();   // the lagging row goes straight into its epilogue
             cur ^= 1;
         }
-        // ---- epilogue: both wave rows concurrently --------------------------------------------------------------------
+        // ---- epilogue: both wave rows concurrently; one specialised, contiguous code path per (activation, residual) ------
+        if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f) {
+            if constexpr (KS) epilogue256<SCONF_ACT_NONE, false, true, JH>(p, acc, cit, wr, wc, lane);
+            else if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
+            else if (p.act == SCONF_ACT_MULAUX)     epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
+            else if (p.resid)                       epilogue256<SCONF_ACT_NONE, true, false, JH>(p, acc, cit, wr, wc, lane);
+            else                                    epilogue256<SCONF_ACT_NONE, false, false, JH>(p, acc, cit, wr, wc, lane);
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int m = cit.m0 + 128 * h + 64 * wr + 16 * i + (lane & 15);
-                if constexpr (!KS) {
-                    const int g = lane >> 4, nlo = cit.n0 + WC * wc + 8 * g, nhi = cit.n0 + WC * wc + 32 + 4 * JH * g;
-                    EpiIn<8> ilo; EpiIn<4 * JH> ihi;
-                    epi_load<8>(p, ilo, m, nlo); epi_load<4 * JH>(p, ihi, m, nhi);
-                    float vlo[8], vhi[4 * JH];
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) vlo[e] = acc[h][i][e >> 2][e & 3];
-#pragma unroll
-                    for (int e = 0; e < 4 * JH; ++e) vhi[e] = acc[h][i][2 + (e >> 2)][e & 3];
-                    epi_apply<8>(p, vlo, ilo, m, nlo, cit.split);
-                    epi_apply<4 * JH>(p, vhi, ihi, m, nhi, cit.split);
-                } else {
-                    const int nb = cit.n0 + 32 * wc + 4 * (lane >> 4);
-                    const int ncol[4] = {nb, nb + 16, nb + 128, nb + 144};
-                    epi_narrow_row(p, acc[h][i], m, ncol, cit.split);
-                }
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2 + JH; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            }
         __builtin_amdgcn_s_barrier();                 // re-align the two wave rows
         cv += gridDim.x;
         if (cv >= sc.total) break;
@@ -346,6 +416,9 @@ static int num_cus_cached() {
 bool sconf_gemm256_eligible(const GemmParams& p, int layout) {
     if (layout != 0 && layout != 2) return false;
     const bool ks = layout == 2;
+    // specialised epilogues: NT {plain, +residual, GELU_DSAVE, MULAUX} (bias / pre-save / f32 output in any of them); TN plain
+    if (ks ? (p.act != SCONF_ACT_NONE || p.resid || p.pre)
+           : !(p.act == SCONF_ACT_NONE || ((p.act == SCONF_ACT_GELU_DSAVE || p.act == SCONF_ACT_MULAUX) && !p.resid))) return false;
     // 32-bit per-lane source offsets relative to a half-tile base
     if ((ks ? 64 : 256) * p.lda * 2 >= (1L << 32) || (ks ? 64 : 256) * p.ldb * 2 >= (1L << 32)) return false;
     const int cus = num_cus_cached();

@@ -19,6 +19,7 @@ struct GemmParams {
     long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
     int k_per_split;                                // multiple of BK
     int splits;
+    int debug;                                      // diagnostics only (SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
 };
 
 __device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -47,38 +48,53 @@ template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, E
     if (epi_uses_aux(p)) loadv<W>(p.aux + (long)m * p.ldaux + n, in.ax);
     if (p.resid) loadv<W>(p.resid + (long)m * p.ldr + n, in.rs);
 }
-template <int W> __device__ __forceinline__ void epi_apply(const GemmParams& p, float (&v)[W], const EpiIn<W>& in, int m, int n, int split) {
+// The math + stores of one run.  ACT >= 0 fixes the activation at compile time (the 256-row kernel dispatches once per
+// work item, so that the instructions an item executes are contiguous); ACT = -1 reads p.act.  bs / ax / rs are the run's
+// bias, aux and residual values (zeros where absent), loaded by the caller - ahead of any store where it matters: on gfx950
+// loads and stores retire through one in-order counter, so a load issued behind a store waits for that store's completion.
+template <int W, int ACT = -1>
+__device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W], const float (&bs)[W], const float (&ax)[W],
+                                               const float (&rs)[W], int m, int n, int split) {
+    const int act = ACT >= 0 ? ACT : p.act;
     if (p.bias) {
-        float bs[W]; loadv<W>(p.bias + n, bs);
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] += bs[e];
     }
-    if (p.act == SCONF_ACT_GELU_DSAVE) {
+    const bool st = p.debug != 1 || v[0] == 1.2345e-30f;
+    if (act == SCONF_ACT_GELU_DSAVE) {
         float dg[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) gelu_both(v[e], v[e], dg[e]);
-        storev<W>(p.pre + (long)m * p.ldpre + n, dg);
-    } else if (p.pre) storev<W>(p.pre + (long)m * p.ldpre + n, v);
-    if (p.act == SCONF_ACT_MULAUX) {
+        if (st) storev<W>(p.pre + (long)m * p.ldpre + n, dg);
+    } else if (p.pre) { if (st) storev<W>(p.pre + (long)m * p.ldpre + n, v); }
+    if (act == SCONF_ACT_MULAUX) {
 #pragma unroll
-        for (int e = 0; e < W; ++e) v[e] *= in.ax[e];
-    } else if (p.act == SCONF_ACT_GELU) {
+        for (int e = 0; e < W; ++e) v[e] *= ax[e];
+    } else if (act == SCONF_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] = geluf_(v[e]);
-    } else if (p.act == SCONF_ACT_SILU) {
+    } else if (act == SCONF_ACT_SILU) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] = siluf_(v[e]);
-    } else if (p.act == SCONF_ACT_DGELU) {
+    } else if (act == SCONF_ACT_DGELU) {
 #pragma unroll
-        for (int e = 0; e < W; ++e) v[e] *= dgeluf_(in.ax[e]);
-    } else if (p.act == SCONF_ACT_DSILU) {
+        for (int e = 0; e < W; ++e) v[e] *= dgeluf_(ax[e]);
+    } else if (act == SCONF_ACT_DSILU) {
 #pragma unroll
-        for (int e = 0; e < W; ++e) v[e] *= dsiluf_(in.ax[e]);
+        for (int e = 0; e < W; ++e) v[e] *= dsiluf_(ax[e]);
     }
 #pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + in.rs[e];
+    for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + rs[e];
+    if (!st) return;
     if (p.out_f32) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
     else           storev<W>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
+}
+template <int W> __device__ __forceinline__ void epi_apply(const GemmParams& p, float (&v)[W], const EpiIn<W>& in, int m, int n, int split) {
+    float bs[W];
+#pragma unroll
+    for (int e = 0; e < W; ++e) bs[e] = 0.f;
+    if (p.bias) loadv<W>(p.bias + n, bs);
+    epi_math_store<W, -1>(p, v, bs, in.ax, in.rs, m, n, split);
 }
 
 // narrow row block (K-strided B: NN / TN): lane (r = lane&15, g = lane>>4) owns row m and, in each of four 16-column tiles
