@@ -47,10 +47,13 @@ int sconf_splitk_reduce(const float* slab, float* out, int64_t splits, int64_t n
  * sconformer_xl.py:14-17, normalisation.py:6-47).  mean/rstd: f32 [M] saved statistics. */
 int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* weight, const float* bias, void* y, int y_dtype,
                    float* mean, float* rstd, int64_t M, int64_t d, float eps, sconf_stream_t stream);
-/* dx = (dres ? dres : 0) + norm'(x)·dy ; dweight/dbias ACCUMULATED. */
+/* dx = (dres ? dres : 0) + norm'(x)·dy ; dweight/dbias ACCUMULATED.  workspace: optional scratch of at least
+ * sconf_norm_bwd_workspace(M, d) floats (per-workgroup column sums, combined in a fixed order); NULL = f32 atomics. */
+int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d);
 int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                    const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype, float* dweight,
-                   float* dbias, int64_t M, int64_t d, float eps, sconf_stream_t stream);
+                   float* dbias, float* workspace, int64_t workspace_floats, int64_t M, int64_t d, float eps,
+                   sconf_stream_t stream);
 
 int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
 /* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */

@@ -10,6 +10,9 @@
 // grid-stride loop of rows, reduced across the workgroup's waves in LDS and flushed with one f32 atomic per
 // column per workgroup.
 #include "common.h"
+#include <stdlib.h>
+
+SCONF_API int sconf_num_cus(void);
 
 namespace {
 
@@ -71,14 +74,43 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(const TI* __restrict__ x,
     }
 }
 
-template <typename TI, typename TG, typename TO, int MODE, int MAXIT>
-__global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy, const TI* __restrict__ x,
+// raw 4-element vectors: a row's loads are issued one row ahead and converted only when consumed
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 v; __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; } };
+template <> struct Raw4<bf16>  { bf16x4 v; __device__ __forceinline__ void get(float (&o)[4]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)v[e]; } };
+template <typename T> __device__ __forceinline__ void raw_load(Raw4<T>& r, const T* p) { r.v = *reinterpret_cast<const decltype(r.v)*>(p); }
+
+template <typename TI, typename TG, int MAXIT> struct BwdRow {
+    Raw4<TI> x[MAXIT]; Raw4<TG> g[MAXIT]; Raw4<float> r[MAXIT]; float mean, rstd;
+    template <int MODE> __device__ __forceinline__ void load(const TG* dy, const TI* xp, const float* stat_mean, const float* stat_rstd,
+                                                             const float* dres, int row, int d, int lane) {
+        mean = (MODE == 0) ? stat_mean[row] : 0.f;
+        rstd = stat_rstd[row];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                raw_load(x[it], xp + (long)row * d + c); raw_load(g[it], dy + (long)row * d + c);
+                if (dres) raw_load(r[it], dres + (long)row * d + c);
+            }
+        }
+    }
+};
+
+// One wave per row, rows strided over the grid; the NEXT row's loads (x, dy, the incoming residual gradient, the row
+// statistics) are issued before the current row's reductions, so the HBM latency overlaps the dependent wave_sum chains.
+// SLAB: the workgroup's column sums go to ws[blockIdx][dw | db][d] (plain stores; norm_bwd_reduce_kernel adds them up) instead
+// of atomics: all workgroups finish together and 512 x 2d atomics on 2d addresses serialise at the end of the kernel.
+template <typename TI, typename TG, typename TO, int MODE, int MAXIT, int NB_WAVES, bool AHEAD, bool SLAB>
+__global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __restrict__ dy, const TI* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ stat_mean,
                                                        const float* __restrict__ stat_rstd, const float* __restrict__ dres,
                                                        TO* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-                                                       int M, int d, float eps) {
+                                                       float* __restrict__ ws, int M, int d, float eps) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * 4 + (threadIdx.x >> 6), nw = gridDim.x * 4;
+    const int wid = blockIdx.x * NB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * NB_WAVES;
     float aw[MAXIT][4], ab[MAXIT][4], wv[MAXIT][4];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -87,18 +119,22 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
         for (int e = 0; e < 4; ++e) { aw[it][e] = 0.f; ab[it][e] = 0.f; wv[it][e] = 0.f; }
         if (c < d) load4(w + c, wv[it]);
     }
+    BwdRow<TI, TG, MAXIT> nxt;
+    if (AHEAD && wid < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, wid, d, lane);
     for (int row = wid; row < M; row += nw) {
-        const TI* xr = x + (long)row * d;
-        const TG* gr = dy + (long)row * d;
-        const float mean = (MODE == 0) ? stat_mean[row] : 0.f;
-        const float rstd = stat_rstd[row];
+        BwdRow<TI, TG, MAXIT> cur;
+        if (AHEAD) {
+            cur = nxt;
+            if (row + nw < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, row + nw, d, lane);
+        } else cur.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, row, d, lane);
+        const float mean = cur.mean, rstd = cur.rstd;
         float xh[MAXIT][4], g[MAXIT][4];
         float s1 = 0.f, s2 = 0.f;                    // sum(g*w), sum(g*w*xhat)  (xhat = raw x for RMS modes)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = it * 256 + lane * 4;
             if (c < d) {
-                load4(xr + c, xh[it]); load4(gr + c, g[it]);
+                cur.x[it].get(xh[it]); cur.g[it].get(g[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float xn = (MODE == 0) ? (xh[it][e] - mean) * rstd : xh[it][e];
@@ -124,7 +160,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
             if (c < d) {
                 float o[4];
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
-                if (dres) load4(dres + (long)row * d + c, r);
+                if (dres) cur.r[it].get(r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = r[e] + rstd * g[it][e] * wv[it][e] - c1 - xh[it][e] * c2;
                 store4(dxr + c, o);
@@ -133,7 +169,7 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
     }
     // cross-wave reduction in LDS, then ONE atomic per column per workgroup (<= 512 workgroups): column atomics from
     // every wave of every workgroup serialise on the few hundred addresses of dw/db.
-    __shared__ float red[4][256];
+    __shared__ float red[NB_WAVES][256];
     const int wvi = threadIdx.x >> 6;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -147,10 +183,17 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(const TG* __restrict__ dy
             for (int e = 0; e < 4; ++e) red[wvi][lane * 4 + e] = pass == 0 ? aw[it][e] : ab[it][e];
             __syncthreads();
             if (wvi == 0 && c < d) {
+                float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float v = red[0][lane * 4 + e] + red[1][lane * 4 + e] + red[2][lane * 4 + e] + red[3][lane * 4 + e];
-                    atomicAdd((pass == 0 ? dw : db) + c + e, v);
+                    v[e] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NB_WAVES; ++k) v[e] += red[k][lane * 4 + e];
+                }
+                if (SLAB) store4(ws + ((long)blockIdx.x * 2 + pass) * d + c, v);
+                else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) atomicAdd((pass == 0 ? dw : db) + c + e, v[e]);
                 }
             }
         }
@@ -170,11 +213,61 @@ int launch_fwd(const void* x, int xdt, const float* w, const float* b, void* y, 
     return 0;
 }
 
+// dw[c] += sum_b ws[b][0][c], db[c] += sum_b ws[b][1][c]: one lane per column, 16 waves stride over the workgroups' slabs
+__global__ __launch_bounds__(1024) void norm_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
+                                                               int nblocks, int d) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;                          // in [0, 2d): dw columns then db columns
+    const int pass = col >= d, c = col - pass * d;
+    float a = 0.f;
+    if (col < 2 * d && (pass == 0 || db)) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = wv;
+        for (; b + 48 < nblocks; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] += ws[((long)(b + 16 * u) * 2 + pass) * d + c];
+        }
+        for (; b < nblocks; b += 16) t[0] += ws[((long)b * 2 + pass) * d + c];
+        a = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    red[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && col < 2 * d && (pass == 0 || db)) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][lane];
+        float* o = (pass == 0 ? dw : db) + c;
+        *o += v;
+    }
+}
+
+// Launch geometry of the backward: NB_WAVES waves per workgroup, <= MAXG workgroups (each wave walks rows wid, wid + nw, ...).
+struct BwdGeo { int nbw, maxg; bool ahead; };
+static BwdGeo bwd_geo(int nit) {
+    static int cus = 0;
+    if (!cus) { const int n = sconf_num_cus(); cus = n > 0 ? n : 256; }
+    BwdGeo g{8, cus, nit <= 4};                       // one workgroup per CU (measured best: 8 waves, next row in flight);
+                                                      // wider rows would spill with a row in flight: load where used
+    if (const char* e = getenv("SCONF_NORM_BWD_CFG")) {      // "waves,maxgrid,ahead" (benchmarking)
+        int a = 8, b = 512, c = 1;
+        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { g.nbw = a == 4 ? 4 : 8; g.maxg = b; g.ahead = c && nit <= 4; }
+    }
+    return g;
+}
+
 template <int MODE, int NIT>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
-               const float* dres, void* dx, int odt, float* dw, float* db, int M, int d, float eps, hipStream_t st) {
-    dim3 grid(min(cdiv(M, 4), 512)), block(256);
-#define L(TI, TG, TO) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, M, d, eps)
+               const float* dres, void* dx, int odt, float* dw, float* db, float* ws, long ws_floats, int M, int d, float eps, hipStream_t st) {
+    const BwdGeo geo = bwd_geo(NIT);
+    dim3 grid(min(cdiv(M, geo.nbw), geo.maxg)), block(64 * geo.nbw);
+    const bool slab = ws && ws_floats >= (long)grid.x * 2 * d;
+#define L4(TI, TG, TO, NBW, AH, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AH, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, M, d, eps)
+#define L(TI, TG, TO) do { \
+    if (geo.nbw == 8) { if (geo.ahead) { if (slab) L4(TI, TG, TO, 8, true, true); else L4(TI, TG, TO, 8, true, false); } \
+                        else           { if (slab) L4(TI, TG, TO, 8, false, true); else L4(TI, TG, TO, 8, false, false); } } \
+    else              { if (geo.ahead) { if (slab) L4(TI, TG, TO, 4, true, true); else L4(TI, TG, TO, 4, true, false); } \
+                        else           { if (slab) L4(TI, TG, TO, 4, false, true); else L4(TI, TG, TO, 4, false, false); } } } while (0)
     if (xdt == SCONF_F32) {
         if (gdt == SCONF_F32) { if (odt == SCONF_F32) L(float, float, float); else L(float, float, bf16); }
         else                  { if (odt == SCONF_F32) L(float, bf16, float);  else L(float, bf16, bf16); }
@@ -183,6 +276,8 @@ int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, 
         else                  { if (odt == SCONF_F32) L(bf16, bf16, float);  else L(bf16, bf16, bf16); }
     }
 #undef L
+#undef L4
+    if (slab) hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, st, ws, dw, db, (int)grid.x, d);
     return 0;
 }
 
@@ -207,17 +302,24 @@ SCONF_API int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* 
     return 0;
 }
 
-// dx = (dres ? dres : 0) + d(norm)/dx . dy ;  dweight/dbias are ACCUMULATED (+=) with f32 atomics.
+// dx = (dres ? dres : 0) + d(norm)/dx . dy ;  dweight/dbias are ACCUMULATED (+=).  `workspace` (optional, >=
+// sconf_norm_bwd_workspace(M, d) floats, contents irrelevant) receives per-workgroup column sums that a second kernel adds
+// into dweight/dbias in a fixed order; without it the workgroups fall back to f32 atomics (slower, order not fixed).
+SCONF_API int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d) {
+    const BwdGeo geo = bwd_geo((int)((d + 255) / 256));
+    return (int64_t)min(cdiv(M, geo.nbw), geo.maxg) * 2 * d;
+}
 SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                              const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype,
-                             float* dweight, float* dbias, int64_t M, int64_t d, float eps, hipStream_t stream) {
+                             float* dweight, float* dbias, float* workspace, int64_t workspace_floats,
+                             int64_t M, int64_t d, float eps, hipStream_t stream) {
     SCONF_REQUIRE(mode >= 0 && mode <= 2, "sconf_norm_bwd: bad mode %d", mode);
     SCONF_REQUIRE(d % 4 == 0 && d <= MAXD && d > 0, "sconf_norm_bwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm_bwd: too many rows");
     if (M == 0) return 0;
-    if (mode == 0) NIT_DISPATCH(launch_bwd, 0, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
-    else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
-    else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, (int)M, (int)d, eps, stream);
+    if (mode == 0) NIT_DISPATCH(launch_bwd, 0, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
+    else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
+    else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
     SCONF_LAUNCH_OK("sconf_norm_bwd");
     return 0;
 }

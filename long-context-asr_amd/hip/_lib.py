@@ -19,7 +19,7 @@ PROTOTYPES = {
     'sconf_gemm_num_splits': [i64, i32],
     'sconf_splitk_reduce': [vp, vp, i64, i64, i32, vp],
     'sconf_norm_fwd': [i32, vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, f32, vp],
-    'sconf_norm_bwd': [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, i64, i64, f32, vp],
+    'sconf_norm_bwd': [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, i64, f32, vp],
     'sconf_cast': [vp, i32, vp, i32, i64, vp],
     'sconf_cast_transpose': [vp, vp, i64, i64, vp],
     'sconf_rotary_qkv': [i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
@@ -45,7 +45,7 @@ PROTOTYPES = {
     'sconf_sumsq': [vp, i64, vp, vp],
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp],
 }
-PLAIN = {'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
+PLAIN = {'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 
 
 def load():

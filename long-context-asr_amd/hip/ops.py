@@ -149,8 +149,10 @@ def norm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, mean: torc
     d = x.shape[-1]; M = x.numel() // d
     if dres is not None: _chk(dres, 'dres', torch.float32)
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
+    nws = int(_lib.load().sconf_norm_bwd_workspace(M, d))               # per-workgroup column sums (no atomics, fixed order)
+    ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     _lib.call('sconf_norm_bwd', NORM_MODE[mode], _p(dy), _dt(dy), _p(x), _dt(x), _p(weight), _p(mean), _p(rstd), _p(dres),
-              _p(dx), _dt(dx), _p(dweight), _p(dbias), M, d, float(eps), _stream())
+              _p(dx), _dt(dx), _p(dweight), _p(dbias), _p(ws), nws, M, d, float(eps), _stream())
     return dx
 
 
