@@ -58,6 +58,11 @@ int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_
 int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
 /* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */
 int sconf_cast_transpose(const float* src, void* dst, int64_t R, int64_t C, sconf_stream_t stream);
+/* One launch for all bf16 weight shadows of a model.  table: device array of n_entries + 1 records of six int64
+ * {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R, C, first 32x32-tile index}; the last record is the sentinel
+ * {0,0,0,0,0,total_tiles}.  Stands in for the per-module weight casts torch.autocast does in the reference
+ * (lcasr/utils/general.py, training loop under autocast) plus the transposed copies the NT dgrad GEMMs read. */
+int sconf_cast_shadows(const void* table, int64_t n_entries, int64_t total_tiles, sconf_stream_t stream);
 
 /* qkv de-interleave "b n (h d qkv) -> qkv b n h d" + NeoX rotary on q,k (attention.py:485,498-507; rotary_emb.py:61-73).
  * bwd != 0: transpose, (dq,dk,dv) -> dqkv written to `qkv`.  cos/sin: f32 [N][D/2]. */

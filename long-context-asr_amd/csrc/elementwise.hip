@@ -38,6 +38,35 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
     }
 }
 
+// All bf16 weight shadows of a model in ONE launch (the per-step refresh after the optimiser has moved the f32 masters).
+// table[e] = {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R, C, first 32x32-tile index of the entry}; entry n is a
+// sentinel holding the total tile count.  Block b finds its entry by binary search over the tile prefix.
+struct ShadowEntry { const float* src; bf16* dst; bf16* dstT; long R, C, tile0; };
+__global__ __launch_bounds__(256) void cast_shadows_kernel(const ShadowEntry* __restrict__ table, int n) {
+    __shared__ float tile[32][33];
+    const long b = blockIdx.x;
+    int lo = 0, hi = n;                                    // table[lo].tile0 <= b < table[hi].tile0
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].tile0 <= b) lo = mid; else hi = mid; }
+    const ShadowEntry e = table[lo];
+    const int R = (int)e.R, C = (int)e.C, tiles_c = (C + 31) >> 5;
+    const int t = (int)(b - e.tile0), r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + 8 * k, c = c0 + tx;
+        const float v = (r < R && c < C) ? e.src[(long)r * C + c] : 0.f;
+        tile[ty + 8 * k][tx] = v;
+        if (e.dst && r < R && c < C) e.dst[(long)r * C + c] = (bf16)v;
+    }
+    if (!e.dstT) return;                                   // uniform per block
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + 8 * k, r = r0 + tx;
+        if (c < C && r < R) e.dstT[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // qkv de-interleave + NeoX rotary.  Reference layout of the qkv projection output is
 // "b n (h d qkv)" (attention.py:485): column (h*D + d)*3 + {0:q, 1:k, 2:v}.  One thread handles
@@ -221,6 +250,18 @@ SCONF_API int sconf_cast_transpose(const float* src, void* dst, int64_t R, int64
     if (R * C == 0) return 0;
     hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(C, 32), cdiv(R, 32)), dim3(256), 0, stream, src, (bf16*)dst, (int)R, (int)C);
     SCONF_LAUNCH_OK("sconf_cast_transpose");
+    return 0;
+}
+
+// table: DEVICE array of n_entries + 1 records of 6 x int64 {src, dst, dstT, R, C, tile0} (see cast_shadows_kernel); the last
+// record is the sentinel {0, 0, 0, 0, 0, total_tiles}.  Replaces the per-weight autocast casts of the reference
+// (torch.autocast, training_tools.py) and their transposed variants with one launch per step.
+SCONF_API int sconf_cast_shadows(const void* table, int64_t n_entries, int64_t total_tiles, hipStream_t stream) {
+    static_assert(sizeof(ShadowEntry) == 48, "table record is 6 x 8 bytes");
+    SCONF_REQUIRE(n_entries >= 0 && total_tiles >= 0 && total_tiles < (1L << 31), "sconf_cast_shadows: bad sizes");
+    if (n_entries == 0 || total_tiles == 0) return 0;
+    hipLaunchKernelGGL(cast_shadows_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, (const ShadowEntry*)table, (int)n_entries);
+    SCONF_LAUNCH_OK("sconf_cast_shadows");
     return 0;
 }
 

@@ -23,33 +23,72 @@ from .hip import ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 
-_wcache: dict = {}
+# ---- bf16 weight shadows ---------------------------------------------------------------------------------------------
+# The GEMMs read bf16 copies of the f32 master weights: a row-major copy (forward, NT) and a transposed copy (dgrad as
+# an NT GEMM).  The copies live in persistent buffers; `refresh_weight_shadows()` (called at the start of every model
+# forward, i.e. after any optimiser step / state-dict load / manual edit) re-derives ALL of them from the masters in one
+# kernel launch, so they can never be older than the forward that uses them.
+class _Shadow:
+    __slots__ = ('w', 'rows', 'cols', 'n', 't')
+
+    def __init__(self, w):
+        self.w = w                                   # keeps the master alive and lets refresh re-read its data_ptr
+        self.rows = w.shape[0]; self.cols = w.numel() // max(w.shape[0], 1)
+        self.n = None; self.t = None
+
+
+_shadows: dict = {}                                  # (data_ptr, shape) -> _Shadow
+_table = {'key': None, 'dev': None, 'tiles': 0}
 
 
 def clear_weight_cache() -> None:
-    """Drop the per-forward bf16 weight copies (call at the start of every model forward)."""
-    _wcache.clear()
+    """Forget every shadow (tests; after re-pointing parameter storage)."""
+    _shadows.clear()
+    _table.update(key=None, dev=None, tiles=0)
+
+
+def refresh_weight_shadows() -> None:
+    """Re-cast all registered shadows from their f32 masters: one launch (sconf_cast_shadows)."""
+    if not _shadows:
+        return
+    ents = list(_shadows.values())
+    key = tuple((e.w.data_ptr(), 0 if e.n is None else e.n.data_ptr(), 0 if e.t is None else e.t.data_ptr()) for e in ents)
+    if key != _table['key']:
+        rows, tile0 = [], 0
+        for e, k in zip(ents, key):
+            rows.append([k[0], k[1], k[2], e.rows, e.cols, tile0])
+            tile0 += ((e.rows + 31) // 32) * ((e.cols + 31) // 32)
+        rows.append([0, 0, 0, 0, 0, tile0])
+        _table.update(key=key, dev=torch.tensor(rows, dtype=torch.int64, device=ents[0].w.device), tiles=tile0)
+    ops.cast_shadows(_table['dev'], len(ents), _table['tiles'])
+
+
+def _shadow(w: torch.Tensor) -> _Shadow:
+    key = (w.data_ptr(), tuple(w.shape))
+    e = _shadows.get(key)
+    if e is None:
+        if w.dtype != F32:
+            raise TypeError('master weights are float32')
+        e = _Shadow(w.detach())
+        _shadows[key] = e
+    return e
 
 
 def wcast(w: torch.Tensor) -> torch.Tensor:
     """bf16 copy of an f32 master weight, viewed 2-D (out_features, in_features*k)."""
-    key = (w.data_ptr(), tuple(w.shape))
-    t = _wcache.get(key)
-    if t is None:
-        t = ops.cast(w.detach().reshape(w.shape[0], -1), BF16)
-        _wcache[key] = t
-    return t
+    e = _shadow(w)
+    if e.n is None:                                  # first use: cast now, refreshed in bulk from the next forward on
+        e.n = ops.cast(w.detach().reshape(e.rows, e.cols), BF16)
+    return e.n
 
 
 def wcast_t(w: torch.Tensor) -> torch.Tensor:
     """Transposed bf16 copy (in_features*k, out_features) of an f32 master weight: dgrad dx = dy W becomes the NT GEMM
     dy (W^T)^T whose B operand is K-contiguous (wide epilogue, no transposed LDS reads).  Weights are a few MB."""
-    key = ('t', w.data_ptr(), tuple(w.shape))
-    t = _wcache.get(key)
-    if t is None:
-        t = ops.cast_transpose(w.detach().reshape(w.shape[0], -1).contiguous())
-        _wcache[key] = t
-    return t
+    e = _shadow(w)
+    if e.t is None:
+        e.t = ops.cast_transpose(w.detach().reshape(e.rows, e.cols).contiguous())
+    return e.t
 
 
 def _zeros_like_param(p: Optional[torch.Tensor]):

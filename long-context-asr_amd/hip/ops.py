@@ -177,6 +177,12 @@ def cast_transpose(w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def cast_shadows(table: torch.Tensor, n_entries: int, total_tiles: int) -> None:
+    """Refresh every bf16 weight shadow listed in `table` (device int64 (n_entries + 1, 6), see sconf.h) in one launch."""
+    _chk(table, 'table', torch.int64)
+    _lib.call('sconf_cast_shadows', _p(table), int(n_entries), int(total_tiles), _stream())
+
+
 def rotary_qkv_fwd(qkv: torch.Tensor, cos: Optional[torch.Tensor], sin: Optional[torch.Tensor], B: int, N: int, H: int, D: int):
     """qkv (B*N, H*D*3) bf16 in the reference's "(h d qkv)" column order -> q,k,v (B,N,H,D) bf16, rotary on q,k.
     cos/sin: (N, D/2) f32 or None (no rotary)."""

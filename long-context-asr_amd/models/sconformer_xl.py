@@ -88,7 +88,7 @@ class SCConformerXL(BaseModel):
         if cached_kvs is not None:
             raise NotImplementedError('cached_kvs is vestigial in the reference (SURVEY.md fact 8) and not supported')
         Fn.ops.require_gpu(audio_signal, 'audio_signal')
-        Fn.clear_weight_cache()
+        Fn.refresh_weight_shadows()
         dec = self.decoder
         B, _, T = audio_signal.shape
         dev = audio_signal.device

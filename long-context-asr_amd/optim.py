@@ -35,6 +35,8 @@ class FlatParams:
             self.data[o:o + p.numel()].copy_(p.data.reshape(-1))
             p.data = self.data[o:o + p.numel()].view(p.shape)
             p.grad = self.grad[o:o + p.numel()].view(p.shape)
+        from . import functional as _Fn
+        _Fn.clear_weight_cache()                              # bf16 shadows registered against the old storage are stale
 
     def zero_grad(self):
         self.grad.zero_()

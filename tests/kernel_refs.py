@@ -104,6 +104,17 @@ def cast(x, dtype): return x.to(dtype)
 def cast_transpose(w): return w.t().contiguous().to(torch.bfloat16)
 
 
+def cast_shadows(table, n_entries, total_tiles):
+    """Reference of sconf_cast_shadows: the table holds RAW addresses (here: of CPU tensors), exactly like the C ABI."""
+    import ctypes
+    for src, dst, dst_t, R, C, _ in table[:n_entries].tolist():
+        w = torch.frombuffer((ctypes.c_float * (R * C)).from_address(src), dtype=torch.float32).view(R, C)
+        if dst:
+            torch.frombuffer((ctypes.c_uint16 * (R * C)).from_address(dst), dtype=torch.bfloat16).view(R, C).copy_(w)
+        if dst_t:
+            torch.frombuffer((ctypes.c_uint16 * (R * C)).from_address(dst_t), dtype=torch.bfloat16).view(C, R).copy_(w.t())
+
+
 def _rot(x, cos, sin, sign=1.0):
     # x (B,N,H,D) f32 ; cos/sin (N, D/2)
     h = x.shape[-1] // 2

@@ -141,6 +141,24 @@ def test_cast(ops):
     assert torch.equal(ops.cast(dev(x.to(BF)), F32).cpu(), x.to(BF).float())
 
 
+def test_cast_shadows(ops):
+    """One launch refreshes row-major and/or transposed bf16 shadows of many ragged weights (bit-exact casts)."""
+    shapes = [(768, 768), (33, 65), (1, 7), (4096, 768), (31, 32), (256, 9)]
+    ws = [dev(rnd(r, c, dtype=F32)) for r, c in shapes]
+    want_n = [True, True, False, True, True, False]; want_t = [True, False, True, True, True, True]
+    dn = [torch.full((r, c), 7.0, dtype=BF, device='cuda') if n else None for (r, c), n in zip(shapes, want_n)]
+    dt = [torch.full((c, r), 7.0, dtype=BF, device='cuda') if t else None for (r, c), t in zip(shapes, want_t)]
+    rows, tile0 = [], 0
+    for w, a, b in zip(ws, dn, dt):
+        rows.append([w.data_ptr(), a.data_ptr() if a is not None else 0, b.data_ptr() if b is not None else 0, w.shape[0], w.shape[1], tile0])
+        tile0 += ((w.shape[0] + 31) // 32) * ((w.shape[1] + 31) // 32)
+    rows.append([0, 0, 0, 0, 0, tile0])
+    ops.cast_shadows(torch.tensor(rows, dtype=torch.int64, device='cuda'), len(ws), tile0)
+    for w, a, b in zip(ws, dn, dt):
+        if a is not None: assert torch.equal(a, w.to(BF))
+        if b is not None: assert torch.equal(b, w.t().contiguous().to(BF))
+
+
 @pytest.mark.parametrize('H,D', [(2, 32), (6, 128)])
 def test_rotary_qkv(ops, H, D):
     import sys
