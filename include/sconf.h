@@ -74,8 +74,8 @@ int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, int y_dtype
 int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype,
                       int64_t M, int64_t C, sconf_stream_t stream);
 
-/* out[n] += sum_m x[m][n]  (bias gradients). */
-int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, sconf_stream_t stream);
+/* out[n] += alpha * sum_m x[m][n]  (bias gradients). */
+int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, sconf_stream_t stream);
 /* zero rows n >= lengths[b] of x[B][N][d] in place (attention.py:511,546-547; convolution.py:109-110). */
 int sconf_mask_rows(void* x, int dtype, const int32_t* lengths, int64_t B, int64_t N, int64_t d, sconf_stream_t stream);
 

@@ -198,10 +198,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// out[n] += sum_m x[m][n]   (bias gradients).  Block = 256 threads = 64 column-quads x 4 row lanes.
+// out[n] += alpha * sum_m x[m][n]   (bias gradients).  Block = 256 threads = 64 column-quads x 4 row lanes.
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, long M, int N, long ld,
-                                                     int rows_per_block) {
+                                                     int rows_per_block, float alpha) {
     __shared__ float sh[4][256];
     const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 256 + cq * 4;
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     for (int e = 0; e < 4; ++e) sh[rl][cq * 4 + e] = a[e];
     __syncthreads();
     const int cc = blockIdx.x * 256 + threadIdx.x;
-    if (cc < N) atomicAdd(out + cc, sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]);
+    if (cc < N) atomicAdd(out + cc, alpha * (sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x]));
 }
 
 // Zero rows n >= len[b] of x[B][N][d] in place (attention.py:511,546-547; convolution.py:109-110).
@@ -322,7 +322,7 @@ SCONF_API int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void
 }
 
 // out[n] += sum over rows (bias gradients of Linear / Conv layers).
-SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, hipStream_t stream) {
+SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, hipStream_t stream) {
     SCONF_REQUIRE(N % 4 == 0 && ld % 4 == 0, "sconf_colsum: N and ld must be multiples of 4");
     if (M == 0 || N == 0) return 0;
     const int cb = cdiv(N, 256);
@@ -330,8 +330,8 @@ SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, in
     const int rpb = cdiv(M, rb);
     rb = cdiv(M, rpb);
     dim3 g(cb, rb), b(256);
-    if (x_dtype == SCONF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), g, b, 0, stream, (const bf16*)x, out, (long)M, (int)N, (long)ld, rpb);
-    else hipLaunchKernelGGL((colsum_kernel<float>), g, b, 0, stream, (const float*)x, out, (long)M, (int)N, (long)ld, rpb);
+    if (x_dtype == SCONF_BF16) hipLaunchKernelGGL((colsum_kernel<bf16>), g, b, 0, stream, (const bf16*)x, out, (long)M, (int)N, (long)ld, rpb, alpha);
+    else hipLaunchKernelGGL((colsum_kernel<float>), g, b, 0, stream, (const float*)x, out, (long)M, (int)N, (long)ld, rpb, alpha);
     SCONF_LAUNCH_OK("sconf_colsum");
     return 0;
 }

@@ -91,24 +91,67 @@ def wcast_t(w: torch.Tensor) -> torch.Tensor:
     return e.t
 
 
-def _zeros_like_param(p: Optional[torch.Tensor]):
-    return None if p is None else torch.zeros(p.shape, dtype=F32, device=p.device)
+# ---- parameter gradients ---------------------------------------------------------------------------------------------
+# Default: the backward functions RETURN parameter gradients and autograd accumulates them (p.grad += g: one add kernel
+# per parameter plus the zero-fills of the temporaries).  With `set_direct_grad(True)` (the training driver does this once
+# its flat gradient buffer is attached to every p.grad) the kernels accumulate straight into p.grad and the functions
+# return None for those inputs.  That is only valid under loss.backward() semantics (never torch.autograd.grad), which is
+# why it is opt-in.  `set_grad_ready_hook(fn)` gets fn(param) after each direct write: the data-parallel bucket logic
+# (parallel.GradSync) listens there, since autograd's post-accumulate hooks do not fire for gradients it never sees.
+_direct = {'on': False, 'hook': None}
 
 
-def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, shape, alpha: float = 1.0) -> torch.Tensor:
-    """dW[N',K'] = alpha * dy^T x  (TN GEMM, split-K over the token dimension when the tile count is small)."""
+def set_direct_grad(on: bool) -> None:
+    _direct['on'] = bool(on)
+
+
+def set_grad_ready_hook(fn) -> None:
+    _direct['hook'] = fn
+
+
+class _G:
+    """Destination of one parameter's gradient inside a backward: p.grad itself (direct mode) or a zeroed temporary."""
+    __slots__ = ('p', 'direct', 't')
+
+    def __init__(self, p: Optional[torch.Tensor], shape=None):
+        self.p = p
+        if p is None:
+            self.direct, self.t = False, None
+            return
+        g = p.grad
+        self.direct = bool(_direct['on'] and g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == p.shape)
+        shape = tuple(p.shape) if shape is None else tuple(shape)
+        self.t = g.view(shape) if self.direct else torch.zeros(shape, dtype=F32, device=p.device)
+
+    def out(self):
+        """What the backward returns for this input."""
+        if self.p is None:
+            return None
+        if self.direct:
+            if _direct['hook'] is not None:
+                _direct['hook'](self.p)
+            return None
+        return self.t.view(self.p.shape)
+
+
+def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, w: torch.Tensor, alpha: float = 1.0):
+    """dW[N',K'] (+)= alpha * dy^T x  (TN GEMM, split-K over the token dimension when the tile count is small)."""
     Mtok, Nout = dy16.shape
     Kin = x16.shape[1]
     sk = ops.pick_split_k(Nout, Kin, Mtok)
-    return ops.gemm(dy16, x16, 'tn', alpha=alpha, out_dtype=F32, split_k=sk).reshape(shape)
+    g = _G(w, (Nout, Kin))
+    if g.direct:
+        ops.gemm(dy16, x16, 'tn', alpha=alpha, out_dtype=F32, split_k=sk, accum=g.t)
+        return g.out()
+    return ops.gemm(dy16, x16, 'tn', alpha=alpha, out_dtype=F32, split_k=sk).reshape(w.shape)
 
 
 def _bgrad(dy16: torch.Tensor, bias: Optional[torch.Tensor], alpha: float = 1.0):
     if bias is None:
         return None
-    out = torch.zeros(bias.shape, dtype=F32, device=bias.device)
-    ops.colsum_(dy16, out)
-    return out if alpha == 1.0 else out * alpha
+    g = _G(bias)
+    ops.colsum_(dy16, g.t, alpha)
+    return g.out()
 
 
 # =================================================================================================
@@ -120,16 +163,15 @@ class NormFn(Function):
         x = x.contiguous()
         y, mean, rstd = ops.norm_fwd(x, weight, bias, mode, eps, out_dtype)
         ctx.save_for_backward(x, weight, mean, rstd)
-        ctx.mode, ctx.eps, ctx.has_bias = mode, eps, bias is not None
+        ctx.mode, ctx.eps, ctx.P = mode, eps, (weight, bias)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
-        dw = torch.zeros_like(weight)
-        db = torch.zeros_like(weight) if ctx.has_bias else None
-        dx = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, x.dtype, dw, db)
-        return dx, dw, db, None, None, None
+        dw, db = _G(ctx.P[0]), _G(ctx.P[1])
+        dx = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, x.dtype, dw.t, db.t)
+        return dx, dw.out(), db.out(), None, None, None
 
 
 def norm(x, weight, bias, mode='layer_norm', eps=1e-5, out_dtype=F32):
@@ -152,12 +194,14 @@ class FFBlockFn(Function):
             ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t)
         else:
             ctx.save_for_backward(x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t, h, u, a)
-        ctx.cfg = (scale, mode, eps, ckpt, w1.shape, w2.shape, residual)
+        ctx.cfg = (scale, mode, eps, ckpt, residual)
+        ctx.P = (nw, nb, w1, w2, b1, b2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        scale, mode, eps, ckpt, w1s, w2s, residual = ctx.cfg
+        scale, mode, eps, ckpt, residual = ctx.cfg
+        pnw, pnb, pw1, pw2, pb1, pb2 = ctx.P
         t = ctx.saved_tensors
         x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t = t[:11]
         if ckpt >= 1:
@@ -168,14 +212,14 @@ class FFBlockFn(Function):
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
         du = ops.gemm(dy16, w2t, 'nt', aux=u, act='mulaux', alpha=scale)           # (M,4d): dy W2 * gelu'(pre)
-        dw2 = _wgrad(dy16, a, w2s, alpha=scale)
-        db2 = _bgrad(dy16, b2, alpha=scale)
-        dw1 = _wgrad(du, h, w1s)
-        db1 = _bgrad(du, b1)
+        dw2 = _wgrad(dy16, a, pw2, alpha=scale)
+        db2 = _bgrad(dy16, pb2, alpha=scale)
+        dw1 = _wgrad(du, h, pw1)
+        db1 = _bgrad(du, pb1)
         dh = ops.gemm(du, w1t, 'nt')
-        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
-        return dx, dnw, dnb, dw1, dw2, db1, db2, None, None, None, None, None
+        dnw, dnb = _G(pnw), _G(pnb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        return dx, dnw.out(), dnb.out(), dw1, dw2, db1, db2, None, None, None, None, None
 
 
 def ff_block(x, nw, nb, w1, w2, b1, b2, scale=0.5, mode='layer_norm', eps=1e-5, ckpt=0, residual=True):
@@ -200,29 +244,31 @@ class AttnBlockFn(Function):
         o, lse = ops.attn_fwd(q, k, v, lengths, window)                               # padded query rows come back zero
         y = ops.gemm(o.view(B * N, H * D), woh, 'nt', bias=bout, resid=x if residual else None, out_dtype=F32)
         ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wqkv), wcast_t(wout), bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse)
-        ctx.cfg = (B, N, H, D, window, mode, eps, wqkv.shape, wout.shape, residual)
+        ctx.cfg = (B, N, H, D, window, mode, eps, residual)
+        ctx.P = (nw, nb, wqkv, wout, bqkv, bout)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, N, H, D, window, mode, eps, wqs, wos, residual = ctx.cfg
+        B, N, H, D, window, mode, eps, residual = ctx.cfg
+        pnw, pnb, pwq, pwo, pbq, pbo = ctx.P
         x, nw, nb, mean, rstd, wqt, wot, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
         o2 = o.view(B * N, H * D)
         do = ops.gemm(dy16, wot, 'nt')                                                # (M, H*D)
-        dwo = _wgrad(dy16, o2, wos)
-        dbo = _bgrad(dy16, bout)
+        dwo = _wgrad(dy16, o2, pwo)
+        dbo = _bgrad(dy16, pbo)
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, lengths, window)
         dqkv = ops.rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D)
-        dwq = _wgrad(dqkv, h, wqs)
-        dbq = _bgrad(dqkv, bqkv)
+        dwq = _wgrad(dqkv, h, pwq)
+        dbq = _bgrad(dqkv, pbq)
         dh = ops.gemm(dqkv, wqt, 'nt')
         if lengths is not None:
             ops.mask_rows_(dh, lengths, B, N)
-        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
-        return (dx, dnw, dnb, dwq, dwo, dbq, dbo) + (None,) * 11
+        dnw, dnb = _G(pnw), _G(pnb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        return (dx, dnw.out(), dnb.out(), dwq, dwo, dbq, dbo) + (None,) * 11
 
 
 def attn_block(x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B, N, H, D, window=(-1, -1), mode='layer_norm', eps=1e-5,
@@ -251,28 +297,28 @@ class ConvBlockFn(Function):
         y2 = ops.affine_silu_fwd(hc, coef)
         y = ops.gemm(y2, w2h, 'nt', bias=bpw2, resid=x if residual else None, out_dtype=F32)
         ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wpw1), wcast_t(wpw2), bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2)
-        ctx.cfg = (B, N, training, mode, eps, wpw1.shape, wpw2.shape, wdw.shape, residual)
+        ctx.cfg = (B, N, training, mode, eps, residual)
+        ctx.P = (nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, wpw2, bpw2)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, N, training, mode, eps, w1s, w2s, wdws, residual = ctx.cfg
+        B, N, training, mode, eps, residual = ctx.cfg
+        pnw, pnb, pw1, pb1, pwdw, pbdw, pbrnw, pbrnb, pw2, pb2 = ctx.P
         x, nw, nb, mean, rstd, w1t, w2t, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2 = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
         dy2 = ops.gemm(dy16, w2t, 'nt')                                               # (M, d)
-        dw2 = _wgrad(dy16, y2, w2s)
-        db2 = _bgrad(dy16, bpw2)
-        ddw = torch.zeros(wdw2.shape, dtype=F32, device=x.device)
-        dbdw = torch.zeros(wdw2.shape[0], dtype=F32, device=x.device)
-        dbrnw = torch.zeros_like(brn_w); dbrnb = torch.zeros_like(brn_w)
-        dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw, dbdw, dbrnw, dbrnb)
-        dw1 = _wgrad(dg, h, w1s)
-        db1 = _bgrad(dg, bpw1)
+        dw2 = _wgrad(dy16, y2, pw2)
+        db2 = _bgrad(dy16, pb2)
+        ddw, dbdw, dbrnw, dbrnb = _G(pwdw, wdw2.shape), _G(pbdw), _G(pbrnw), _G(pbrnb)
+        dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw.t, dbdw.t, dbrnw.t, dbrnb.t)
+        dw1 = _wgrad(dg, h, pw1)
+        db1 = _bgrad(dg, pb1)
         dh = ops.gemm(dg, w1t, 'nt')
-        dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw, dnb)
-        return (dx, dnw, dnb, dw1, db1, ddw.reshape(wdws), dbdw, dbrnw, dbrnb, None, None, None, dw2, db2) + (None,) * 7
+        dnw, dnb = _G(pnw), _G(pnb)
+        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        return (dx, dnw.out(), dnb.out(), dw1, db1, ddw.out(), dbdw.out(), dbrnw.out(), dbrnb.out(), None, None, None, dw2, db2) + (None,) * 7
 
 
 def conv_block(x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, running_std, nbt, wpw2, bpw2, lengths, B, N,
@@ -297,29 +343,30 @@ class SelfCondFn(Function):
         p = ops.softmax_fwd(logits, False, BF16)
         y = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32)
         ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wff), wcast_t(wre), bff, bre, hn, p)
-        ctx.cfg = (has_norm, mode, eps, wff.shape, wre.shape)
+        ctx.cfg = (has_norm, mode, eps)
+        ctx.P = (nw, nb, wff, bff, wre, bre)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        has_norm, mode, eps, wfs, wrs = ctx.cfg
+        has_norm, mode, eps = ctx.cfg
+        pnw, pnb, pwf, pbf, pwr, pbr = ctx.P
         x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p = ctx.saved_tensors
         dy = dy.contiguous()
         dy16 = ops.cast(dy, BF16)
         dp = ops.gemm(dy16, wrt, 'nt')                                                # (M, V+1)
-        dwr = _wgrad(dy16, p, wrs)
-        dbr = _bgrad(dy16, bre)
+        dwr = _wgrad(dy16, p, pwr)
+        dbr = _bgrad(dy16, pbr)
         dl = ops.softmax_bwd(p, dp, False, BF16)
-        dwf = _wgrad(dl, hn, wfs)
-        dbf = _bgrad(dl, bff)
+        dwf = _wgrad(dl, hn, pwf)
+        dbf = _bgrad(dl, pbf)
         dhn = ops.gemm(dl, wft, 'nt')
         if has_norm:
-            dnw = torch.zeros_like(nw); dnb = _zeros_like_param(nb)
-            dx = ops.norm_bwd(dhn, x, nw, mean, rstd, mode, eps, dy, F32, dnw, dnb)
-        else:
-            dnw = dnb = None
-            dx = dy + ops.cast(dhn, F32)
-        return dx, dnw, dnb, dwf, dbf, dwr, dbr, None, None, None
+            dnw, dnb = _G(pnw), _G(pnb)
+            dx = ops.norm_bwd(dhn, x, nw, mean, rstd, mode, eps, dy, F32, dnw.t, dnb.t)
+            return dx, dnw.out(), dnb.out(), dwf, dbf, dwr, dbr, None, None, None
+        dx = dy + ops.cast(dhn, F32)
+        return dx, None, None, dwf, dbf, dwr, dbr, None, None, None
 
 
 def selfcond_block(x, nw, nb, wff, bff, wre, bre, has_norm=True, mode='layer_norm', eps=1e-5):
@@ -345,27 +392,28 @@ class HeadFn(Function):
         logits = ops.gemm(hn, wfh, 'nt', bias=bff, out_dtype=F32)
         out = logits if return_logits else ops.softmax_fwd(logits, True, F32)
         ctx.save_for_backward(nw, nb, wcast_t(wff), bff, hn, out, *saved_norm)
-        ctx.cfg = (n_norms, mode, eps, return_logits, wff.shape)
+        ctx.cfg = (n_norms, mode, eps, return_logits)
+        ctx.P = (nw, nb, wff, bff)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        n_norms, mode, eps, return_logits, wfs = ctx.cfg
+        n_norms, mode, eps, return_logits = ctx.cfg
+        pnw, pnb, pwf, pbf = ctx.P
         nw, nb, wft, bff, hn, out = ctx.saved_tensors[:6]
         sn = ctx.saved_tensors[6:]
         dout = dout.contiguous()
         dl = ops.cast(dout, BF16) if return_logits else ops.softmax_bwd(out, dout, True, BF16)
-        dwf = _wgrad(dl, hn, wfs)
-        dbf = _bgrad(dl, bff)
+        dwf = _wgrad(dl, hn, pwf)
+        dbf = _bgrad(dl, pbf)
         g = ops.gemm(dl, wft, 'nt')                                                    # (M,d) bf16
-        dnw = torch.zeros_like(nw) if n_norms > 0 else None
-        dnb = _zeros_like_param(nb) if n_norms > 0 else None
+        dnw, dnb = _G(pnw if n_norms > 0 else None), _G(pnb if n_norms > 0 else None)
         for i in reversed(range(n_norms)):
             xin, mean, rstd = sn[3 * i:3 * i + 3]
-            g = ops.norm_bwd(g, xin, nw, mean, rstd, mode, eps, None, F32, dnw, dnb)
+            g = ops.norm_bwd(g, xin, nw, mean, rstd, mode, eps, None, F32, dnw.t, dnb.t)
         if n_norms == 0:
             g = ops.cast(g, F32)
-        return g, dnw, dnb, dwf, dbf, None, None, None, None
+        return g, dnw.out(), dnb.out(), dwf, dbf, None, None, None, None
 
 
 def decoder_head(x, nw, nb, wff, bff, n_norms=1, mode='layer_norm', eps=1e-5, return_logits=False):
@@ -391,32 +439,31 @@ class SubsampleFn(Function):
         s = ops.sub_silu_transpose(pre2.view(B * N, F8, C))                            # (B*N, C*F8)
         x = ops.gemm(s, woh, 'nt', bias=bout, out_dtype=F32)
         ctx.save_for_backward(audio, w0f, wd1f, wd2f, wcast_t(wp1), wcast_t(wp2), wcast_t(wout), bp1, bp2, bout, b0, d1, pre1, d2, pre2, s)
-        ctx.cfg = (w0.shape, wd1.shape, wp1.shape, wd2.shape, wp2.shape, wout.shape)
+        ctx.P = (w0, b0, wd1, bd1, wp1, bp1, wd2, bd2, wp2, bp2, wout, bout)
         return x.view(B, N, -1)
 
     @staticmethod
     def backward(ctx, dx):
-        s0, sd1, sp1, sd2, sp2, so = ctx.cfg
+        pw0, pb0, pwd1, pbd1, pwp1, pbp1, pwd2, pbd2, pwp2, pbp2, pwo, pbo = ctx.P
         audio, w0f, wd1f, wd2f, wp1t, wp2t, wot, bp1, bp2, bout, b0, d1, pre1, d2, pre2, s = ctx.saved_tensors
         B, N, F8, C = d2.shape
         dev = dx.device
         dx16 = ops.cast(dx.contiguous().view(B * N, -1), BF16)
         ds = ops.gemm(dx16, wot, 'nt')                                                 # (B*N, C*F8)
-        dwo = _wgrad(dx16, s, so)
-        dbo = _bgrad(dx16, bout)
+        dwo = _wgrad(dx16, s, pwo)
+        dbo = _bgrad(dx16, pbo)
         dpre2 = ops.sub_silu_transpose(pre2.view(B * N, F8, C), ds).view(-1, C)
-        dwp2 = _wgrad(dpre2, d2.view(-1, C), sp2)
-        dbp2 = _bgrad(dpre2, bp2)
+        dwp2 = _wgrad(dpre2, d2.view(-1, C), pwp2)
+        dbp2 = _bgrad(dpre2, pbp2)
         dd2 = ops.gemm(dpre2, wp2t, 'nt').view(d2.shape)
-        dwd2 = torch.zeros(C, 9, dtype=F32, device=dev); dbd2 = torch.zeros(C, dtype=F32, device=dev)
-        dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2, dbd2).view(-1, C)
-        dwp1 = _wgrad(dpre1, d1.view(-1, C), sp1)
-        dbp1 = _bgrad(dpre1, bp1)
+        dwd2, dbd2 = _G(pwd2, (C, 9)), _G(pbd2)
+        dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2.t, dbd2.t).view(-1, C)
+        dwp1 = _wgrad(dpre1, d1.view(-1, C), pwp1)
+        dbp1 = _bgrad(dpre1, pbp1)
         dd1 = ops.gemm(dpre1, wp1t, 'nt').view(d1.shape)
-        dwd1 = torch.zeros(C, 9, dtype=F32, device=dev); dbd1 = torch.zeros(C, dtype=F32, device=dev)
-        dw0 = torch.zeros(C, 9, dtype=F32, device=dev); db0 = torch.zeros(C, dtype=F32, device=dev)
-        ops.sub_stage01_bwd_(dd1, audio, w0f, b0, wd1f, dw0, db0, dwd1, dbd1)          # conv0 recomputed; no (B,T/2,F/2,C) grads
-        return (None, dw0.reshape(s0), db0, dwd1.reshape(sd1), dbd1, dwp1, dbp1, dwd2.reshape(sd2), dbd2, dwp2, dbp2, dwo, dbo)
+        dwd1, dbd1, dw0, db0 = _G(pwd1, (C, 9)), _G(pbd1), _G(pw0, (C, 9)), _G(pb0)
+        ops.sub_stage01_bwd_(dd1, audio, w0f, b0, wd1f, dw0.t, db0.t, dwd1.t, dbd1.t)  # conv0 recomputed; no (B,T/2,F/2,C) grads
+        return (None, dw0.out(), db0.out(), dwd1.out(), dbd1.out(), dwp1, dbp1, dwd2.out(), dbd2.out(), dwp2, dbp2, dwo, dbo)
 
 
 def subsample(audio, w0, b0, wd1, bd1, wp1, bp1, wd2, bd2, wp2, bp2, wout, bout):

@@ -26,7 +26,7 @@ PROTOTYPES = {
     'sconf_rotary_qkv': [i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_softmax_fwd': [i32, vp, i32, vp, i32, i64, i64, vp],
     'sconf_softmax_bwd': [i32, vp, i32, vp, i32, vp, i32, i64, i64, vp],
-    'sconf_colsum': [vp, i32, vp, i64, i64, i64, vp],
+    'sconf_colsum': [vp, i32, vp, i64, i64, i64, f32, vp],
     'sconf_mask_rows': [vp, i32, vp, i64, i64, i64, vp],
     'sconf_attn_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, i32, i32, f32, vp],
     'sconf_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],

@@ -60,13 +60,16 @@ def _chk(t: torch.Tensor, name: str, dtype=None):
 # ------------------------------------------------------------------------------------------------
 def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[torch.Tensor] = None,
          resid: Optional[torch.Tensor] = None, aux: Optional[torch.Tensor] = None, act: str = 'none',
-         alpha: float = 1.0, out_dtype: torch.dtype = torch.bfloat16, save_pre: bool = False, split_k: int = 1):
+         alpha: float = 1.0, out_dtype: torch.dtype = torch.bfloat16, save_pre: bool = False, split_k: int = 1,
+         accum: Optional[torch.Tensor] = None):
     """C[M,N] = resid + alpha * act(A·B + bias)   (bf16 operands, f32 accumulate).
 
     layout 'nt': a (M,K), b (N,K) — y = x W^T;  'nn': a (M,K), b (K,N) — dx = dy W;  'tn': a (K,M), b (K,N) — dW = dy^T x.
     act 'dgelu'/'dsilu' multiplies by the activation derivative evaluated at aux (M,N) bf16.
     save_pre returns (C, pre) with pre = A·B + bias in bf16 (act 'gelu_dsave': pre = gelu'(A·B + bias), the factor the
     backward multiplies by with act 'mulaux').  split_k > 1 needs out_dtype float32.
+    accum (f32 (M,N)): the product is ADDED into it in place (accum += alpha * A·B) and returned - weight gradients going
+    straight into the optimiser's flat gradient buffer.
     """
     _chk(a, 'a', torch.bfloat16); _chk(b, 'b', torch.bfloat16)
     if layout == 'nt':
@@ -77,10 +80,17 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
         K, M = a.shape; K2, N = b.shape
     if K != K2:
         raise ValueError(f'gemm {layout}: inner dims differ: {tuple(a.shape)} x {tuple(b.shape)}')
+    if accum is not None:
+        _chk(accum, 'accum', torch.float32)
+        if accum.numel() != M * N or bias is not None or resid is not None or act != 'none' or save_pre:
+            raise ValueError('gemm accum: needs an (M,N) f32 tensor and the plain epilogue')
+        out_dtype = torch.float32
     out_f32 = out_dtype == torch.float32
     splits = _lib.load().sconf_gemm_num_splits(K, int(split_k)) if split_k > 1 else 1
     if splits > 1:                                                     # deterministic split-K: partial slabs + fixed-order reduce
         c = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
+    elif accum is not None:
+        c = resid = accum                                              # out = accum + alpha * A·B, element-wise in place
     else:
         c = torch.empty(M, N, dtype=out_dtype, device=a.device)
     pre = torch.empty(M, N, dtype=torch.bfloat16, device=a.device) if save_pre else None
@@ -94,8 +104,8 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
     _lib.call('sconf_gemm_bf16', LAYOUT[layout], _p(a), _p(b), _p(c), M, N, K, a.stride(0), b.stride(0), N,
               _p(bias), _p(resid), N, _p(aux), N, _p(pre), N, float(alpha), ACT[act], int(out_f32), int(split_k), _stream())
     if splits > 1:
-        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-        _lib.call('sconf_splitk_reduce', _p(c), _p(out), splits, M * N, 0, _stream())
+        out = accum if accum is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
+        _lib.call('sconf_splitk_reduce', _p(c), _p(out), splits, M * N, int(accum is not None), _stream())
         c = out
     return (c, pre) if save_pre else c
 
@@ -220,11 +230,11 @@ def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, log: bool, out_dtype: torch.d
     return dx
 
 
-def colsum_(x: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    """out[n] += sum_m x[m, n]  (in place, f32)."""
+def colsum_(x: torch.Tensor, out: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
+    """out[n] += alpha * sum_m x[m, n]  (in place, f32)."""
     _chk(x, 'x'); _chk(out, 'out', torch.float32)
     N = x.shape[-1]; M = x.numel() // N
-    _lib.call('sconf_colsum', _p(x), _dt(x), _p(out), M, N, N, _stream())
+    _lib.call('sconf_colsum', _p(x), _dt(x), _p(out), M, N, N, float(alpha), _stream())
     return out
 
 

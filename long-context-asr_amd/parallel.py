@@ -45,28 +45,51 @@ class GradSync:
         self.pending = [0] * len(self.buckets)
         self.handles = []
         self._hooks = []
+        self._index = {id(p): i for i, p in enumerate(params)}
+        self._seen, self._expect = {}, None                 # direct-write counts of this backward / of the first one
         if self.world > 1:
             for i, p in enumerate(params):
                 if p.requires_grad:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
 
+    def on_grad_ready(self, p: torch.nn.Parameter) -> None:
+        """A backward kernel has accumulated this parameter's gradient straight into the flat buffer
+        (functional.set_direct_grad): autograd's post-accumulate hook will not fire for it, so count it here."""
+        i = self._index.get(id(p))
+        if i is None or self.world == 1:
+            return
+        # A parameter used by several blocks (the decoder inside every self-conditioning layer) is written several times
+        # per backward.  The first backward only counts the writes; later ones release the parameter on its last write.
+        self._seen[i] = self._seen.get(i, 0) + 1
+        if self._expect is not None and self._seen[i] == self._expect.get(i, 0):
+            self._ready(i)
+
     def reset(self):
         self.pending = [n for (_, _, n) in self.buckets]
         self.handles = []
+        self._seen = {}
+
+    def _ready(self, i):
+        b = self.param_bucket[i]
+        self.pending[b] -= 1
+        if self.pending[b] == 0:
+            s, e, _ = self.buckets[b]
+            self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _make_hook(self, i):
         def hook(_p):
-            b = self.param_bucket[i]
-            self.pending[b] -= 1
-            if self.pending[b] == 0:
-                s, e, _ = self.buckets[b]
-                self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._ready(i)
         return hook
 
     def finish(self):
         """Wait for the in-flight all-reduces; reduce any bucket whose hooks did not all fire (unused parameters)."""
         if self.world > 1:
+            if self._expect is None:
+                self._expect = dict(self._seen)
+            elif any(n > self._expect.get(i, 0) for i, n in self._seen.items()):
+                raise RuntimeError('GradSync: a parameter received more direct gradient writes than in the first backward; '
+                                   'its bucket may have been reduced early (the graph must not change between steps)')
             for b, n in enumerate(self.pending):
                 if n > 0:
                     s, e, _ = self.buckets[b]

@@ -13,6 +13,7 @@ from typing import Optional
 import torch
 
 from .losses import CTCLoss
+from . import functional as Fn
 from .optim import MADGRAD
 from .parallel import GradSync
 
@@ -46,7 +47,13 @@ class Trainer:
         out = self.model(audio, length=lengths)
         loss = self.ctc(out['final_posteriors'].transpose(0, 1), targets, out['length'], target_lengths)
         gb = self.global_batch or B * self.sync.world
-        (loss / (T * gb) * 100).backward()
+        # parameter gradients are accumulated by the backward kernels straight into the flat gradient buffer (no per-
+        # parameter add / zero-fill launches); valid because this is a plain .backward() into pre-attached .grad views
+        Fn.set_direct_grad(True); Fn.set_grad_ready_hook(self.sync.on_grad_ready)
+        try:
+            (loss / (T * gb) * 100).backward()
+        finally:
+            Fn.set_direct_grad(False); Fn.set_grad_ready_hook(None)
         self.sync.finish()
         self.opt.step(max_norm=self.clip_value)
         self.opt.zero_grad()

@@ -40,7 +40,10 @@ def _dsilu(x):
 
 
 def gemm(a, b, layout='nt', bias=None, resid=None, aux=None, act='none', alpha=1.0, out_dtype=torch.bfloat16,
-         save_pre=False, split_k=1):
+         save_pre=False, split_k=1, accum=None):
+    if accum is not None:
+        accum += gemm(a, b, layout, alpha=alpha, out_dtype=f32).reshape(accum.shape)
+        return accum
     A, Bm = a.to(f32), b.to(f32)
     if layout == 'nt': acc = A @ Bm.t()
     elif layout == 'nn': acc = A @ Bm
@@ -149,8 +152,8 @@ def softmax_bwd(y, dy, log, out_dtype):
     return dx.to(out_dtype)
 
 
-def colsum_(x, out):
-    out += x.to(f32).reshape(-1, x.shape[-1]).sum(0)
+def colsum_(x, out, alpha=1.0):
+    out += alpha * x.to(f32).reshape(-1, x.shape[-1]).sum(0)
     return out
 
 

@@ -54,6 +54,30 @@ def test_wiring_against_reference_fixture(emulated_ops, case):
             assert float((got - torch.from_numpy(fx[k]).float()).abs().max()) < 2e-3, k
 
 
+def test_direct_gradient_accumulation_matches_autograd(emulated_ops):
+    """The training driver lets the backward kernels accumulate into pre-attached .grad buffers (flat gradient buffer)
+    instead of returning gradients to autograd: same gradients; the ready-hook fires once per write (parameters shared by
+    several blocks are written, and announced, several times: parallel.GradSync counts them)."""
+    import lcasr_amd.functional as Fn
+    fx = load_golden('tiny_ln_ragged')
+    ref = run_step(build_from_fixture(fx), fx)['grads']
+    m = build_from_fixture(fx)
+    for p in m.parameters():
+        p.grad = torch.full_like(p, 0.25)                      # accumulate ON TOP of what is there
+    seen = []
+    Fn.set_direct_grad(True); Fn.set_grad_ready_hook(lambda p: seen.append(id(p)))
+    try:
+        got = run_step(m, fx)['grads']
+    finally:
+        Fn.set_direct_grad(False); Fn.set_grad_ready_hook(None)
+    for k, g in got.items():
+        assert torch.allclose(g - 0.25, ref[k], rtol=1e-4, atol=1e-5 * float(ref[k].abs().max()) + 1e-7), k
+    ids = [id(p) for p in m.parameters() if p.requires_grad]
+    assert set(seen) == set(ids)
+    shared = {id(p) for p in m.decoder.parameters()}          # the decoder also runs inside every self-conditioning layer
+    assert all(seen.count(i) == 1 for i in ids if i not in shared) and all(seen.count(i) >= 1 for i in shared)
+
+
 def test_eval_mode_uses_running_stats(emulated_ops):
     import sys
     from oracle import sconformer_ref as O
