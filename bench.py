@@ -40,37 +40,58 @@ CONFIGS = {
 PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
 
 
+GEMM_KERNELS = {0: 'gemm_kernel<NT> (128x128 tile)', 1: 'gemm256_kernel<false, 2> (NT, 256x256 tile)',
+                2: 'gemm256_kernel<false, 1> (NT, 256x192 tile)', 3: 'gemm256_kernel<true, 2> (TN, 256x256 tile)'}
+
+
 class GemmTimer:
-    """HIP-event timing of every NT GEMM launch (the dominant kernel) on the stream it is launched on.
+    """HIP-event timing, on the stream it is launched on, of every launch of the dominant GEMM kernel: the variant
+    (sconf_gemm_variant tells which kernel a problem runs on) that carries the most FLOPs in a warm-up step.
     Events are created and recorded once BEFORE the timed region (event creation grows a driver pool and stalls the
     stream for tens of ms when it happens mid-run); inside the timed region events are only re-recorded."""
 
     def __init__(self):
-        self.pool, self.used, self.flops, self.enabled, self.count_only, self.calls = [], 0, 0.0, False, False, 0
+        self.pool, self.used, self.enabled, self.count_only, self.calls = [], 0, False, False, 0
+        self.log = []                                                 # (variant, flops) per timed launch
+        self.warm_flops = {}                                          # variant -> flops of one warm-up step
+        self.only = None                                              # the variant timed in the timed region
 
     def install(self):
         import lcasr_amd.hip.ops as ops
+        from lcasr_amd.hip import _lib
         inner = ops.gemm
         timer = self
+        acts = ops.ACT
 
         def gemm(a, b, layout='nt', **kw):
-            if layout != 'nt' or not (timer.enabled or timer.count_only):
+            if not (timer.enabled or timer.count_only):
                 return inner(a, b, layout, **kw)
-            if timer.count_only:
+            if layout == 'nt': (m, k), n = a.shape, b.shape[0]
+            elif layout == 'nn': (m, k), n = a.shape, b.shape[1]
+            else: (k, m), n = a.shape, b.shape[1]
+            var = _lib.load().sconf_gemm_variant(ops.LAYOUT[layout], m, n, k, a.stride(0), b.stride(0), int(kw.get('split_k', 1)),
+                                                 acts[kw.get('act', 'none')], int(kw.get('resid') is not None or kw.get('accum') is not None and kw.get('split_k', 1) == 1),
+                                                 int(bool(kw.get('save_pre'))))
+            if layout == 'nn': var = 0
+            if timer.count_only:                                      # warm-up step: which kernel carries the most FLOPs?
+                timer.warm_flops[var] = timer.warm_flops.get(var, 0.0) + 2.0 * m * n * k
                 timer.calls += 1
                 return inner(a, b, layout, **kw)
-            if timer.used + 2 > len(timer.pool):
+            if var != timer.only or timer.used + 2 > len(timer.pool):
                 return inner(a, b, layout, **kw)
             e0, e1 = timer.pool[timer.used], timer.pool[timer.used + 1]
             timer.used += 2
             e0.record()
             out = inner(a, b, layout, **kw)
             e1.record()
-            timer.flops += 2.0 * a.shape[0] * b.shape[0] * a.shape[1]
+            timer.log.append((var, 2.0 * m * n * k))
             return out
         ops.gemm = gemm
 
     def prepare(self, n_launches):
+        # events only around the dominant kernel's launches: ~100 event records per step instead of ~350, which would
+        # themselves cost about 1 ms per step
+        self.only = min(self.warm_flops, key=lambda v: (-self.warm_flops[v], v)) if self.warm_flops else None
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_launches)]
         for e in self.pool:
             e.record()                                                # force lazy creation now
@@ -79,12 +100,18 @@ class GemmTimer:
     def summary(self):
         if not self.used:
             return None
-        ms = sum(self.pool[i].elapsed_time(self.pool[i + 1]) for i in range(0, self.used, 2))
-        n = self.used // 2
-        ach = self.flops / (ms * 1e-3)
-        return dict(bound='mfma', kernel='gemm_kernel<NT> (sconf_gemm_bf16 layout 0)', achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
+        per = {}
+        for i, (var, fl) in enumerate(self.log):
+            ms = self.pool[2 * i].elapsed_time(self.pool[2 * i + 1])
+            d = per.setdefault(var, [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl
+        top = max(per, key=lambda v: per[v][1])
+        n, ms, fl = per[top]
+        ach = fl / (ms * 1e-3)
+        tot = sum(self.warm_flops.values()) or 1.0
+        others = {GEMM_KERNELS.get(v, str(v)): round(f / tot, 3) for v, f in sorted(self.warm_flops.items())}
+        return dict(bound='mfma', kernel=GEMM_KERNELS.get(top, str(top)), achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
                     unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=None, launches=n,
-                    avg_launch_us=round(ms * 1e3 / n, 2))
+                    avg_launch_us=round(ms * 1e3 / n, 2), gemm_flop_share_by_kernel=others)
 
 
 def host_cores() -> int:

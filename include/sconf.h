@@ -41,6 +41,10 @@ int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C, int64_t M
                     int split_k, sconf_stream_t stream);
 
 int sconf_gemm_num_splits(int64_t K, int split_k);
+/* Which kernel sconf_gemm_bf16 runs for a problem (bookkeeping for benchmarks): 0 = 128x128-tile kernel, 1 / 2 = 256-row NT
+ * kernel with 256 / 192-wide tiles, 3 = 256x256 TN kernel; -1 = invalid arguments. */
+int sconf_gemm_variant(int layout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int split_k, int act,
+                       int has_resid, int has_pre);
 int sconf_splitk_reduce(const float* slab, float* out, int64_t splits, int64_t n, int accumulate, sconf_stream_t stream);
 
 /* Row norms over the last dim d <= 2048 (apex FusedLayerNorm/FusedRMSNorm, torch LayerNorm, local RMSNorm:

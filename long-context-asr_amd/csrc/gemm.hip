@@ -367,6 +367,22 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     return 0;
 }
 
+// Which kernel sconf_gemm_bf16 runs for a problem (diagnostics / benchmark bookkeeping; same decision code as the launch):
+// 0 = gemm_kernel (128x128 tile, 4 waves), 1 = gemm256_kernel<NT, 256 wide>, 2 = gemm256_kernel<NT, 192 wide>,
+// 3 = gemm256_kernel<TN>.
+SCONF_API int sconf_gemm_variant(int layout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int split_k, int act,
+                                 int has_resid, int has_pre) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return -1;
+    GemmParams p{};
+    p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldb = ldb; p.act = act;
+    p.resid = has_resid ? reinterpret_cast<const float*>(8) : nullptr;      // only tested for null
+    p.pre = has_pre ? reinterpret_cast<bf16*>(8) : nullptr;
+    p.k_per_split = cdiv(cdiv(K, BK), split_k) * BK;
+    p.splits = cdiv(K, p.k_per_split);
+    if (getenv("SCONF_GEMM_NO_256") || !sconf_gemm256_eligible(p, layout)) return 0;
+    return layout == 2 ? 3 : (sconf_gemm256_width(p, layout) == 256 ? 1 : 2);
+}
+
 // Number of K-splits sconf_gemm_bf16 will actually use for (K, split_k): the caller sizes the slab buffer with it.
 SCONF_API int sconf_gemm_num_splits(int64_t K, int split_k) {
     const int nkt = cdiv(K, BK);

@@ -428,6 +428,8 @@ bool sconf_gemm256_eligible(const GemmParams& p, int layout) {
     return (long)(p.M / TM) * (p.N / w) * p.splits * 4 >= 3L * cus;
 }
 
+int sconf_gemm256_width(const GemmParams& p, int layout) { return pick_width(p, layout, num_cus_cached()); }
+
 int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
     static bool attr_set = false;
     const size_t shmem = 2 * BUF;

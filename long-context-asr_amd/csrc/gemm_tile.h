@@ -131,4 +131,5 @@ __device__ __forceinline__ void epi_wide_row(const GemmParams& p, const f32x4 (&
 
 // 256x256-tile kernel (gemm256.hip).  Returns false when the problem does not meet its shape requirements.
 bool sconf_gemm256_eligible(const gemm_tile::GemmParams& p, int layout);
+int  sconf_gemm256_width(const gemm_tile::GemmParams& p, int layout);      // 256 or 192 (NT), 0 = not eligible
 int  sconf_gemm256_launch(const gemm_tile::GemmParams& p, int layout, hipStream_t stream);

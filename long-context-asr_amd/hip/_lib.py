@@ -46,7 +46,7 @@ PROTOTYPES = {
     'sconf_sumsq': [vp, i64, vp, vp],
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp],
 }
-PLAIN = {'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
+PLAIN = {'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 
 
 def load():
