@@ -137,6 +137,17 @@ int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, 
                   const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths, const float* grad_out,
                   float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
 
+/* ---- forward-only inference helpers ------------------------------------------------------------------
+ * Overlap-average of sliding-window posteriors, fetch_logits (lcasr/eval/utils.py:45-111): for W equally long windows
+ * logp (W,n,C) f32, window w starting at output row pos0 + w*stride:  acc (N,C) += sum of exp(logp) over the windows covering
+ * each row, count (N) += how many cover it (both accumulated, so a ragged last window is a second call with W = 1);
+ * sconf_overlap_finalize writes out = log(acc / count) for the first N rows (utils.py:107-111). */
+int sconf_overlap_add_exp(const float* logp, int64_t W, int64_t n, int64_t C, int64_t stride, int64_t pos0, float* acc,
+                          float* count, int64_t N, sconf_stream_t stream);
+int sconf_overlap_finalize(const float* acc, const float* count, float* out, int64_t N, int64_t C, sconf_stream_t stream);
+/* idx[m] = argmax_c x[m][c], first index on ties: GreedyCTCDecoder.forward (lcasr/decoding/greedy.py:19). */
+int sconf_argmax_rows(const float* x, int64_t M, int64_t C, int32_t* idx, sconf_stream_t stream);
+
 /* Fused MADGRAD + global-norm clip over flat f32 buffers (lcasr/optim/madgrad.py:81-212, exp/train.py:46-61). */
 int sconf_sumsq(const float* g, int64_t n, double* out, sconf_stream_t stream);
 int sconf_madgrad_step(float* p, const float* g, float* grad_sum_sq, float* s, const float* x0, void* bf16_shadow,

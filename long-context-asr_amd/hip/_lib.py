@@ -43,6 +43,9 @@ PROTOTYPES = {
     'sconf_sub_silu_transpose': [i32, vp, vp, vp, i64, i64, i64, vp],
     'sconf_ctc_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_ctc_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_overlap_add_exp': [vp, i64, i64, i64, i64, i64, vp, vp, i64, vp],
+    'sconf_overlap_finalize': [vp, vp, vp, i64, i64, vp],
+    'sconf_argmax_rows': [vp, i64, i64, vp, vp],
     'sconf_sumsq': [vp, i64, vp, vp],
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp],
 }

@@ -444,3 +444,30 @@ def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow: Optional[torch.Tensor], sums
     for t, n in ((p, 'p'), (g, 'g'), (grad_sum_sq, 'grad_sum_sq'), (s, 's'), (x0, 'x0')): _chk(t, n, torch.float32)
     _lib.call('sconf_madgrad_step', _p(p), _p(g), _p(grad_sum_sq), _p(s), _p(x0), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
               float(grad_scale), float(lr), float(momentum), float(eps), float(weight_decay), int(k), _stream())
+
+
+# ------------------------------------------------------------------------------------------------
+# forward-only inference helpers (sliding-window transcription)
+# ------------------------------------------------------------------------------------------------
+def overlap_add_exp_(logp: torch.Tensor, acc: torch.Tensor, count: torch.Tensor, pos0: int, stride: int) -> None:
+    """acc[pos0 + w*stride + t] += exp(logp[w, t]), count[...] += 1 for W windows logp (W,n,C) f32 (in place, gather form)."""
+    _chk(logp, 'logp', torch.float32); _chk(acc, 'acc', torch.float32); _chk(count, 'count', torch.float32)
+    W, n, Cc = logp.shape
+    _lib.call('sconf_overlap_add_exp', _p(logp), W, n, Cc, int(stride), int(pos0), _p(acc), _p(count), acc.shape[0], _stream())
+
+
+def overlap_finalize(acc: torch.Tensor, count: torch.Tensor, n_rows: int) -> torch.Tensor:
+    """log(acc / count) for the first n_rows rows."""
+    _chk(acc, 'acc', torch.float32); _chk(count, 'count', torch.float32)
+    out = torch.empty(n_rows, acc.shape[1], dtype=torch.float32, device=acc.device)
+    _lib.call('sconf_overlap_finalize', _p(acc), _p(count), _p(out), n_rows, acc.shape[1], _stream())
+    return out
+
+
+def argmax_rows(x: torch.Tensor) -> torch.Tensor:
+    """int32 argmax over the last dim of an f32 (M,C) tensor, first index on ties."""
+    _chk(x, 'x', torch.float32)
+    Cc = x.shape[-1]; M = x.numel() // Cc
+    idx = torch.empty(M, dtype=torch.int32, device=x.device)
+    _lib.call('sconf_argmax_rows', _p(x), M, Cc, _p(idx), _stream())
+    return idx

@@ -194,7 +194,60 @@ def madgrad_case(MADGRAD):
     print('[madgrad] oracle matches reference; wrote fixture')
 
 
+def infer_case(SC):
+    """Sliding-window inference: the reference's own fetch_logits + GreedyCTCDecoder on a tiny eval model.
+    lcasr.utils.audio_tools (torchaudio/librosa) is only used by unrelated helpers of that file: a two-function stand-in
+    module lets lcasr/eval/utils.py import."""
+    from oracle import sconformer_ref as O, infer_ref as I
+    at = types.ModuleType('lcasr.utils.audio_tools'); at.total_frames = lambda s: int(s * 100); at.total_seconds = lambda f: f / 100
+    sys.modules['lcasr.utils.audio_tools'] = at
+    for name, path in [('lcasr.eval', REF + '/lcasr/eval'), ('lcasr.decoding', REF + '/lcasr/decoding')]:
+        m = types.ModuleType(name); m.__path__ = [path]; sys.modules[name] = m
+    from lcasr.eval.utils import fetch_logits
+    from lcasr.decoding.greedy import GreedyCTCDecoder
+    kw = dict(TINY, default_norm='layer_norm')
+    torch.manual_seed(12345)
+    model = SC(**kw)
+    g = torch.Generator().manual_seed(11)
+    model.train()
+    with torch.no_grad():
+        for _ in range(3):                                       # move the BatchRenorm running statistics off their init
+            model(torch.randn(2, 80, 256, generator=g))
+    model.eval(); model.device = 'cpu'
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    spec = torch.randn(1, 80, 1000, generator=g)
+
+    class Tok:                                                   # fetch_logits only asks the tokenizer for its size
+        def vocab_size(self): return kw['vocab_size']
+
+    class Args: config = {'audio_chunking': {'size': 512, 'overlap': 128}}
+
+    cfg = O.make_config(**kw)
+    fx = dict(spec=spec.numpy())
+    for k, v in kw.items(): fx['cfg.' + k] = np.array(v)
+    for k, v in np_sd(sd).items(): fx['w.' + k] = v
+    dec = GreedyCTCDecoder(tokenizer=None, blank_id=model.decoder.num_classes - 1)
+    cases = [(256, 64), (256, 0), (2048, 0), (-1, -1), (320, 160), (1000, 0), (500, 0)]
+    fx['cases'] = np.array(cases)
+    for ci, (sl, ov) in enumerate(cases):
+        ref = fetch_logits(Args, model, spec.clone(), sl, ov, Tok(), use_tqdm=False)
+        sl_r, ov_r = (512, 128) if sl == -1 else (sl, ov)
+        mine = I.fetch_logits(sd, cfg, spec, sl_r, ov_r, kw['vocab_size'])
+        err = float(np.abs(ref - mine).max())
+        ids = dec(torch.from_numpy(ref), decode=False)
+        assert ids == I.greedy_decode(ref, model.decoder.num_classes - 1)
+        print(f'[infer seq_len={sl} overlap={ov}] rows={ref.shape[0]} oracle-vs-reference max|d|={err:.2e} greedy tokens={len(ids)}')
+        assert ref.shape == mine.shape and err < 2e-5, err
+        fx[f'logits.{ci}'] = ref
+        fx[f'greedy.{ci}'] = np.array(ids, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, 'infer_tiny.npz'), **fx)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == 'infer':             # regenerate only the inference fixture
+        SC, _, _ = load_reference()
+        torch.set_num_threads(8)
+        return infer_case(SC)
     assert os.path.isdir(REF), 'reference not present: this script only runs in the development container'
     os.makedirs(GOLD, exist_ok=True)
     SC, attention_ref, MADGRAD = load_reference()
@@ -206,6 +259,7 @@ def main():
     run_case(SC, C1, 2, 1024, None, 'c1_scalars', save_all_grads=False, save_weights=False, max_abs_tol=2e-4)
     attention_cases(attention_ref)
     madgrad_case(MADGRAD)
+    infer_case(SC)
 
 
 if __name__ == '__main__':

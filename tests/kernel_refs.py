@@ -400,3 +400,18 @@ def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow, sumsq, max_norm, grad_scale,
     z = x0.addcdiv(s, rms, value=-1)
     p.mul_(1 - ck).add_(z, alpha=ck)
     if shadow is not None: shadow.copy_(p)
+
+
+def overlap_add_exp_(logp, acc, count, pos0, stride):
+    W, n, _ = logp.shape
+    for w in range(W):                                         # the reference's order: window after window
+        p = pos0 + w * stride
+        acc[p:p + n] += torch.exp(logp[w]); count[p:p + n] += 1
+
+
+def overlap_finalize(acc, count, n_rows):
+    return torch.log(acc[:n_rows] / count[:n_rows, None])
+
+
+def argmax_rows(x):
+    return torch.argmax(x.reshape(-1, x.shape[-1]), dim=-1).to(torch.int32)

@@ -131,3 +131,29 @@ def test_unsupported_options_fail_loudly():
                dict(conv_norm='batch_norm'), dict(fourier_pos_enc=True)):
         with pytest.raises(NotImplementedError):
             SCConformerXL(vocab_size=31, n_layers=1, d_model=32, n_heads=1, head_dim=32, subsampling_conv_channels=8, **kw)
+
+
+@pytest.mark.parametrize('batched', [False, True])
+def test_fetch_logits_and_greedy_decode_against_reference_fixture(emulated_ops, batched):
+    """Sliding-window inference host logic (window plan, positions, batching of equal windows, greedy decode) with the
+    kernel references standing in for the HIP ops: must track the reference's fetch_logits output to bf16 noise."""
+    from lcasr_amd.eval.utils import fetch_logits, window_plan
+    from lcasr_amd.decoding.greedy import GreedyCTCDecoder
+    fx = load_golden('infer_tiny')
+    m = build_from_fixture(fx).eval()
+
+    class Tok:
+        def vocab_size(self): return int(fx['cfg.vocab_size'])
+
+    class Args: config = {'audio_chunking': {'size': 512, 'overlap': 128}}
+
+    spec = torch.from_numpy(fx['spec'])
+    dec = GreedyCTCDecoder(tokenizer=None, blank_id=m.decoder.num_classes - 1)
+    for ci, (sl, ov) in enumerate(fx['cases'].tolist()):
+        got = fetch_logits(Args, m, spec, sl, ov, Tok(), use_tqdm=False, batched=batched, max_batch=3)
+        ref = fx[f'logits.{ci}']
+        assert got.shape == ref.shape
+        d = np.abs(got - ref)
+        assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (sl, ov, float(d.max()), float(d.mean()))
+        assert dec(torch.from_numpy(ref), decode=False) == fx[f'greedy.{ci}'].tolist()
+    assert window_plan(1000, 256, 64)[-1] == (768, 232) and window_plan(100, 256, 0) == [(0, 100)]

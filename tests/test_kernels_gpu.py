@@ -367,3 +367,26 @@ def test_madgrad_matches_reference_fixture(ops):
         ops.madgrad_step_(p, g, gss, s, x0, shadow, sq, 0.8, 1.0, 3e-3, 0.9, 1e-6, 0.0, step)
         close(p, flat(f'p{step + 1}'), name=f'madgrad step {step}', tol=1e-5)
         assert torch.equal(shadow, p.to(BF))
+
+
+# ------------------------------------------------------------------------------------------------ inference helpers
+def test_overlap_average_and_argmax(ops):
+    torch.manual_seed(3)
+    C, n, W, stride = 128, 29, 5, 21
+    lp = torch.log_softmax(torch.randn(W, n, C), -1)
+    N = 200
+    acc, cnt = torch.zeros(N, C), torch.zeros(N)
+    R.overlap_add_exp_(lp, acc, cnt, 7, stride)
+    lp2 = torch.log_softmax(torch.randn(1, 13, C), -1)
+    R.overlap_add_exp_(lp2, acc, cnt, 7 + (W - 1) * stride + n - 4, 13)
+    a, c = torch.zeros(N, C, device='cuda'), torch.zeros(N, device='cuda')
+    ops.overlap_add_exp_(dev(lp), a, c, 7, stride)
+    ops.overlap_add_exp_(dev(lp2), a, c, 7 + (W - 1) * stride + n - 4, 13)
+    assert torch.equal(c.cpu(), cnt)
+    assert torch.allclose(a.cpu(), acc, rtol=1e-5, atol=1e-7)
+    rows = 7 + (W - 1) * stride + n - 4 + 13
+    got = ops.overlap_finalize(a[7:].contiguous(), c[7:].contiguous(), rows - 7)
+    assert torch.allclose(got.cpu(), R.overlap_finalize(acc[7:], cnt[7:], rows - 7), rtol=1e-5, atol=1e-6)
+    x = torch.randn(1001, 4096)
+    x[5, 100] = x[5, 3000] = 9.0; x[6] = 0.0                   # ties: first index wins
+    assert torch.equal(ops.argmax_rows(dev(x)).cpu(), R.argmax_rows(x))

@@ -122,3 +122,30 @@ def test_full_size_properties_c3_shape():
     # 2e-3, so the per-row total posterior drifts by a few 1e-2 over 2048 steps (torch's f32 CTC has the same limit).
     assert float(lp.grad.sum(-1).abs().max()) < 6e-2
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
+
+
+@pytest.mark.gpu
+def test_fetch_logits_batched_windows_and_greedy_on_gpu():
+    """f3: sliding-window inference through the HIP path vs the reference's fetch_logits output (fixture), batched windows
+    vs one-at-a-time, and greedy decoding (HIP argmax) vs the reference decoder's token ids."""
+    from lcasr_amd.eval.utils import fetch_logits
+    from lcasr_amd.decoding.greedy import GreedyCTCDecoder
+    fx = load_golden('infer_tiny')
+    m = build_from_fixture(fx, 'cuda').eval()
+
+    class Tok:
+        def vocab_size(self): return int(fx['cfg.vocab_size'])
+
+    class Args: config = {'audio_chunking': {'size': 512, 'overlap': 128}}
+
+    spec = torch.from_numpy(fx['spec'])
+    dec = GreedyCTCDecoder(tokenizer=None, blank_id=m.decoder.num_classes - 1)
+    for ci, (sl, ov) in enumerate(fx['cases'].tolist()):
+        seq = fetch_logits(Args, m, spec, sl, ov, Tok(), use_tqdm=False, batched=False)
+        bat = fetch_logits(Args, m, spec, sl, ov, Tok(), use_tqdm=False, batched=True, max_batch=3)
+        ref = fx[f'logits.{ci}']
+        assert seq.shape == ref.shape == bat.shape
+        d = np.abs(seq - ref)
+        assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (sl, ov, float(d.max()), float(d.mean()))
+        assert float(np.abs(seq - bat).max()) < 2e-3, float(np.abs(seq - bat).max())   # same kernels, other batch size
+        assert dec(torch.from_numpy(ref).cuda(), decode=False) == fx[f'greedy.{ci}'].tolist()

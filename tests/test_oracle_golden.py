@@ -88,3 +88,20 @@ def test_oracle_window_semantics_match_attention_ref():
         o = torch.einsum('bhij,bjhd->bihd', s.masked_fill(mask, float('-inf')).softmax(-1), v)
         o = o.masked_fill((torch.arange(N)[None, :] >= lens[:, None])[:, :, None, None], 0.0)
         assert float((o - torch.from_numpy(fx[name + '.o'])).abs().max()) < 1e-5, name
+
+
+def test_inference_oracle_matches_reference_fetch_logits_and_greedy():
+    """oracle/infer_ref.py against the outputs of the reference's own fetch_logits / GreedyCTCDecoder (infer_tiny.npz)."""
+    import torch
+    from oracle import infer_ref as I
+    fx = load_golden('infer_tiny')
+    kw = golden_cfg(fx)
+    cfg = O.make_config(**kw)
+    sd = golden_state_dict(fx)
+    spec = torch.from_numpy(fx['spec'])
+    for ci, (sl, ov) in enumerate(fx['cases'].tolist()):
+        if sl == -1: sl, ov = 512, 128                          # the config defaults the fixture was generated with
+        got = I.fetch_logits(sd, cfg, spec, sl, ov, kw['vocab_size'])
+        ref = fx[f'logits.{ci}']
+        assert got.shape == ref.shape and float(np.abs(got - ref).max()) < 2e-5
+        assert I.greedy_decode(ref, kw['vocab_size']) == fx[f'greedy.{ci}'].tolist()
