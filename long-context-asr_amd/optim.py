@@ -96,6 +96,53 @@ class MADGRAD(torch.optim.Optimizer):
         self.last_sumsq = self._sumsq
         return loss
 
+    # ---- checkpoint compatibility with lcasr.optim.madgrad.MADGRAD (optim/madgrad.py:95-130) --------------------------
+    # The reference keeps, per parameter, state {'grad_sum_sq', 's', 'x0'} (created lazily at the first step) and the step
+    # counter as a 1-element long tensor under the non-parameter key 'k'.  Here that state lives in flat buffers; state_dict()
+    # / load_state_dict() translate, so checkpoints written by either implementation resume in the other.
+    _PRIVATE = ('params', '_gss', '_s', '_x0')
+
+    def state_dict(self):
+        state, groups, idx = {}, [], 0
+        for group, fp in zip(self.param_groups, self.flat):
+            ids = []
+            for p, o in zip(fp.params, fp.offsets):
+                n = p.numel()
+                if self.k > 0:
+                    state[idx] = {name: group[key][o:o + n].view(p.shape).clone()
+                                  for name, key in (('grad_sum_sq', '_gss'), ('s', '_s'), ('x0', '_x0'))}
+                ids.append(idx); idx += 1
+            g = {k: v for k, v in group.items() if k not in self._PRIVATE}
+            g['params'] = ids
+            groups.append(g)
+        if self.k > 0:
+            state['k'] = torch.tensor([self.k], dtype=torch.long)
+        return {'state': state, 'param_groups': groups}
+
+    @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        groups, state = state_dict['param_groups'], state_dict['state']
+        if len(groups) != len(self.param_groups):
+            raise ValueError('loaded state dict has a different number of parameter groups')
+        idx = 0
+        for saved, group, fp in zip(groups, self.param_groups, self.flat):
+            if len(saved['params']) != len(fp.params):
+                raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
+            for k, v in saved.items():
+                if k not in self._PRIVATE:
+                    group[k] = v
+            for p, o in zip(fp.params, fp.offsets):
+                st = state.get(idx, state.get(str(idx)))
+                n = p.numel()
+                if st is not None:
+                    for name, key in (('grad_sum_sq', '_gss'), ('s', '_s'), ('x0', '_x0')):
+                        group[key][o:o + n].copy_(st[name].reshape(-1).to(group[key]))
+                else:                                            # the reference would create it at the next step
+                    group['_gss'][o:o + n].zero_(); group['_s'][o:o + n].zero_(); group['_x0'][o:o + n].copy_(fp.data[o:o + n])
+                idx += 1
+        k = state.get('k', None)
+        self.k = int(k.reshape(-1)[0]) if k is not None else 0
+
     def grad_norm(self) -> float:
         """Host value of the last step's global gradient norm (syncs)."""
         return math.sqrt(float(self._sumsq))

@@ -41,12 +41,15 @@ class Trainer:
         fp = self.opt.flat[0]
         self.sync = GradSync(fp.params, fp.grad, fp.offsets, bucket_bytes)
 
-    def step(self, audio, lengths, targets, target_lengths):
-        """One optimiser step; returns the (device) summed CTC loss of this rank's shard."""
+    def step(self, audio, lengths, targets, target_lengths, norm_frames: Optional[int] = None, norm_batch: Optional[int] = None):
+        """One optimiser step; returns the (device) summed CTC loss of this rank's shard.
+        The loss is scaled by 100 / (norm_frames * norm_batch): the reference divides by the CONSTANT chunk_size * batch_size
+        (exp/train.py:275), so ragged last chunks and shrunken batches weigh less; defaults: this batch's width / batch."""
         B, _, T = audio.shape
         out = self.model(audio, length=lengths)
         loss = self.ctc(out['final_posteriors'].transpose(0, 1), targets, out['length'], target_lengths)
-        gb = self.global_batch or B * self.sync.world
+        T = norm_frames or T
+        gb = norm_batch or self.global_batch or B * self.sync.world
         # parameter gradients are accumulated by the backward kernels straight into the flat gradient buffer (no per-
         # parameter add / zero-fill launches); valid because this is a plain .backward() into pre-attached .grad views
         Fn.set_direct_grad(True); Fn.set_grad_ready_hook(self.sync.on_grad_ready)
@@ -58,3 +61,26 @@ class Trainer:
         self.opt.step(max_norm=self.clip_value)
         self.opt.zero_grad()
         return loss.detach()
+
+    def train_recording(self, audio, audio_lengths, chunk_size: int, chunk_overlap: int, targets_for_chunk):
+        """One batch of long recordings, chunk by chunk (exp/train.py:174-293 with backwards_every = backprop_every = 1, the
+        paper configs): audio (B, F, T_total), audio_lengths (B,) frames.  Recordings that have run out drop out of the batch
+        (`selection_mask`), the last chunk of each is ragged (per-sample lengths -> the varlen attention / masking path).
+        targets_for_chunk(ix, chunk) -> (targets (B', S), target_lengths (B',)) for the rows alive in chunk ix (the text side
+        of the reference's chunker is data plumbing; the benchmark feeds synthetic targets).  Returns the per-chunk losses."""
+        from .utils.dataloading import chunk_spectogram, plan_chunks
+        plan = plan_chunks(chunk_spectogram(audio, chunk_size, chunk_overlap), audio_lengths, chunk_overlap)
+        nominal = audio.shape[0] * self.sync.world
+        losses = []
+        for ix, c in enumerate(plan):
+            keep = c['audio_lengths'] > 0                       # an exactly exhausted recording: the reference feeds a zero-length
+            if not bool(keep.all()):                            # row and lands in its NaN-skip branch; here the row is dropped
+                c = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in c.items()}
+            if c['audio'].shape[0] == 0:
+                continue
+            tg, tl = targets_for_chunk(ix, c)
+            if int(tl.max()) == 0:                              # train.py:186-187: nothing to align in this chunk
+                continue
+            losses.append(self.step(c['audio'].contiguous(), c['audio_lengths'], tg, tl, norm_frames=chunk_size, norm_batch=nominal))
+        return losses
+

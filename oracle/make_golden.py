@@ -194,6 +194,58 @@ def madgrad_case(MADGRAD):
     print('[madgrad] oracle matches reference; wrote fixture')
 
 
+def schedule_and_checkpoint_case(MADGRAD):
+    """f2/f4: the reference's SequenceWarmupManager / CosineLRScheduler step sequences, chunk_spectogram, and the layout of
+    MADGRAD.state_dict() after two steps (so a resumed optimiser can be checked against steps 3-4 of madgrad.npz)."""
+    from lcasr.utils.scheduling import SequenceWarmupManager, CosineLRScheduler
+    fx = {}
+    cfgs = [dict(increase_every=5, stop_after=23, start_after=3, initial_sequence_length=512, initial_batch_size=64, max_sequence_length=6000),
+            dict(increase_every=4, stop_after=100, start_after=0, initial_sequence_length=2048, initial_batch_size=3, max_sequence_length=16384,
+                 increase_by_multiplier=1.5, batch_size_multiplier=0.7),
+            dict(increase_every=-1, stop_after=10, start_after=0, initial_sequence_length=2048, initial_batch_size=8, max_sequence_length=4096)]
+    for ci, c in enumerate(cfgs):
+        m = SequenceWarmupManager(**c)
+        rows = []
+        for i in range(60):
+            ch, sl, bs = m.step(steps=1 + (i % 3 == 0))
+            rows.append([int(ch), sl, bs, m.cur_position, m.steps_since_last_increase])
+        fx[f'swm.{ci}'] = np.array(rows, dtype=np.int64)
+        fx[f'swm_cfg.{ci}'] = np.array([c.get(k, d) for k, d in (('increase_every', 0), ('stop_after', 0), ('start_after', 0), ('initial_sequence_length', 0),
+                                       ('initial_batch_size', 0), ('max_sequence_length', 0), ('increase_by_multiplier', 2.0), ('batch_size_multiplier', 0.5))], dtype=np.float64)
+    p = torch.nn.Parameter(torch.zeros(3))
+    opt = torch.optim.SGD([p], lr=1.0)
+    sch = CosineLRScheduler(opt, warmup_steps=7, peak_value=3e-3, final_value=0.0)
+    lrs = []
+    for i in range(12):
+        opt.step(); sch.step(); lrs.append(sch.get_last_lr()[0])
+    sch.set_cosine_schedule(total_recordings=40, cur_podcast=12)
+    for i in range(30):
+        opt.step(); sch.step(); lrs.append(sch.get_last_lr()[0])
+    fx['cosine_lrs'] = np.array(lrs, dtype=np.float64)
+    fx['cosine_state_keys'] = np.array(sorted(k for k in sch.state_dict().keys()))
+    # optimiser state after 2 of the 4 steps of madgrad.npz
+    mg = np.load(os.path.join(GOLD, 'madgrad.npz'))
+    shapes = [(37,), (8, 16), (3, 5, 7)]
+    params = [torch.nn.Parameter(torch.from_numpy(mg[f'p0.{i}'].copy())) for i in range(3)]
+    opt = MADGRAD(params, lr=3e-3, momentum=0.9, weight_decay=0.0, eps=1e-6)
+    for step in range(2):
+        for i, q in enumerate(params): q.grad = torch.from_numpy(mg[f'g{step}.{i}'].copy())
+        torch.nn.utils.clip_grad_norm_(params, 0.8)
+        opt.step()
+    sd = opt.state_dict()
+    assert sorted(map(str, sd['state'].keys())) == ['0', '1', '2', 'k'], sd['state'].keys()
+    for i in range(3):
+        for name in ('grad_sum_sq', 's', 'x0'):
+            fx[f'opt.state.{i}.{name}'] = sd['state'][i][name].numpy()
+        assert sorted(sd['state'][i].keys()) == ['grad_sum_sq', 's', 'x0']
+    fx['opt.k'] = sd['state']['k'].numpy()
+    g0 = sd['param_groups'][0]
+    fx['opt.group_keys'] = np.array(sorted(g0.keys()))
+    fx['opt.group_params'] = np.array(g0['params'])
+    np.savez_compressed(os.path.join(GOLD, 'schedules.npz'), **fx)
+    print('[schedules/checkpoint] wrote fixture; optimizer group keys:', sorted(g0.keys()), 'scheduler keys:', sorted(sch.state_dict().keys()))
+
+
 def infer_case(SC):
     """Sliding-window inference: the reference's own fetch_logits + GreedyCTCDecoder on a tiny eval model.
     lcasr.utils.audio_tools (torchaudio/librosa) is only used by unrelated helpers of that file: a two-function stand-in
@@ -244,10 +296,10 @@ def infer_case(SC):
 
 
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == 'infer':             # regenerate only the inference fixture
-        SC, _, _ = load_reference()
+    if len(sys.argv) > 1 and sys.argv[1] in ('infer', 'sched'):  # regenerate only one of the later fixtures
+        SC, _, MADGRAD = load_reference()
         torch.set_num_threads(8)
-        return infer_case(SC)
+        return infer_case(SC) if sys.argv[1] == 'infer' else schedule_and_checkpoint_case(MADGRAD)
     assert os.path.isdir(REF), 'reference not present: this script only runs in the development container'
     os.makedirs(GOLD, exist_ok=True)
     SC, attention_ref, MADGRAD = load_reference()
@@ -260,6 +312,7 @@ def main():
     attention_cases(attention_ref)
     madgrad_case(MADGRAD)
     infer_case(SC)
+    schedule_and_checkpoint_case(MADGRAD)
 
 
 if __name__ == '__main__':

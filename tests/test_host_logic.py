@@ -157,3 +157,106 @@ def test_fetch_logits_and_greedy_decode_against_reference_fixture(emulated_ops, 
         assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (sl, ov, float(d.max()), float(d.mean()))
         assert dec(torch.from_numpy(ref), decode=False) == fx[f'greedy.{ci}'].tolist()
     assert window_plan(1000, 256, 64)[-1] == (768, 232) and window_plan(100, 256, 0) == [(0, 100)]
+
+
+def test_chunk_plan_schedules_and_optimizer_state_layout():
+    """f2/f4 host logic against the reference-generated fixture (schedules.npz): SequenceWarmupManager and CosineLRScheduler
+    step sequences, the chunk plan of exp/train.py:174-201 (closed form), MADGRAD.state_dict layout."""
+    from lcasr_amd.utils.scheduling import SequenceWarmupManager, CosineLRScheduler
+    from lcasr_amd.utils.dataloading import chunk_spectogram, plan_chunks
+    fx = load_golden('schedules')
+    names = ('increase_every', 'stop_after', 'start_after', 'initial_sequence_length', 'initial_batch_size', 'max_sequence_length')
+    for ci in range(3):
+        c = fx[f'swm_cfg.{ci}']
+        m = SequenceWarmupManager(**{k: int(v) for k, v in zip(names, c[:6])}, increase_by_multiplier=float(c[6]), batch_size_multiplier=float(c[7]))
+        for i, row in enumerate(fx[f'swm.{ci}'].tolist()):
+            ch, sl, bs = m.step(steps=1 + (i % 3 == 0))
+            assert [int(ch), sl, bs, m.cur_position, m.steps_since_last_increase] == row, (ci, i)
+        m2 = SequenceWarmupManager(**{k: int(v) for k, v in zip(names, c[:6])}); m2.load_state_dict(dict(m.state_dict()))
+        assert m2.state_dict() == m.state_dict()
+    p = torch.nn.Parameter(torch.zeros(3)); opt = torch.optim.SGD([p], lr=1.0)
+    sch = CosineLRScheduler(opt, warmup_steps=7, peak_value=3e-3, final_value=0.0)
+    lrs = []
+    for i in range(12): opt.step(); sch.step(); lrs.append(sch.get_last_lr()[0])
+    sch.set_cosine_schedule(total_recordings=40, cur_podcast=12)
+    for i in range(30): opt.step(); sch.step(); lrs.append(sch.get_last_lr()[0])
+    assert np.allclose(lrs, fx['cosine_lrs'], rtol=1e-12, atol=0)
+    assert sorted(sch.state_dict().keys()) == fx['cosine_state_keys'].tolist()
+    # chunk plan: valid frames of sample b in chunk ix == min(length_b + overlap - frames handed out before, width_ix)
+    spec = torch.arange(3 * 2 * 1000, dtype=torch.float32).view(3, 2, 1000)
+    lens = torch.tensor([1000, 530, 256])
+    for size, ov in ((256, 64), (256, 0), (400, 8)):
+        chunks = chunk_spectogram(spec, size, ov)
+        assert [c.shape[-1] for c in chunks] == [min(size, 1000 - i) for i in range(0, 1000, size - ov)]
+        assert all(torch.equal(c, spec[:, :, i:i + size]) for c, i in zip(chunks, range(0, 1000, size - ov)))
+        for ix, c in enumerate(plan_chunks(chunks, lens.clone(), ov)):
+            start, width = ix * (size - ov), chunks[ix].shape[-1]
+            consumed = 0 if ix == 0 else min(start + ov, 1000)          # frames handed out before this chunk
+            alive = ~(torch.full_like(lens, consumed) > lens)
+            assert torch.equal(c['selection_mask'], alive)
+            # train.py:180 counts `overlap` frames as already seen even in the FIRST chunk (nothing was): a recording that
+            # ends inside chunk 0 is reported `overlap` frames too long - reproduced, not fixed
+            assert torch.equal(c['audio_lengths'], (lens[alive] + ov - consumed).clamp(max=width))
+            assert torch.equal(c['audio'], chunks[ix][alive])
+
+
+def test_madgrad_state_dict_interchanges_with_the_reference(emulated_ops, monkeypatch):
+    """A reference-layout optimizer state (fixture: the reference MADGRAD after steps 1-2 of madgrad.npz) loaded into this
+    MADGRAD continues exactly like the reference (steps 3-4 of madgrad.npz); state_dict() emits the same layout."""
+    import lcasr_amd.optim as OPT
+    import kernel_refs
+    monkeypatch.setattr(OPT, 'ops', kernel_refs)
+    fx, mg = load_golden('schedules'), load_golden('madgrad')
+    params = [torch.nn.Parameter(torch.from_numpy(mg[f'p2.{i}'].copy())) for i in range(3)]
+    opt = OPT.MADGRAD(params, lr=1.0, momentum=0.5)
+    ref_sd = {'state': {i: {n: torch.from_numpy(fx[f'opt.state.{i}.{n}'].copy()) for n in ('grad_sum_sq', 's', 'x0')} for i in range(3)},
+              'param_groups': [dict(lr=3e-3, momentum=0.9, weight_decay=0.0, eps=1e-6, decouple_decay=False, params=[0, 1, 2])]}
+    ref_sd['state']['k'] = torch.from_numpy(fx['opt.k'].copy())
+    opt.load_state_dict(ref_sd)
+    assert opt.k == 2 and opt.param_groups[0]['lr'] == 3e-3 and opt.param_groups[0]['momentum'] == 0.9
+    sd = opt.state_dict()
+    assert sorted(map(str, sd['state'].keys())) == ['0', '1', '2', 'k'] and int(sd['state']['k'][0]) == 2
+    assert sorted(sd['param_groups'][0].keys()) == fx['opt.group_keys'].tolist() and sd['param_groups'][0]['params'] == fx['opt.group_params'].tolist()
+    for i in range(3):
+        for n in ('grad_sum_sq', 's', 'x0'):
+            assert torch.equal(sd['state'][i][n], ref_sd['state'][i][n]) and sd['state'][i][n].shape == params[i].shape
+    for step in (2, 3):
+        for i, q in enumerate(params): q.grad.copy_(torch.from_numpy(mg[f'g{step}.{i}']))
+        opt.step(max_norm=0.8)
+        for i, q in enumerate(params):
+            assert float((q.detach() - torch.from_numpy(mg[f'p{step + 1}.{i}'])).abs().max()) < 1e-6, (step, i)
+
+
+def test_checkpoint_roundtrip_layout(tmp_path, emulated_ops, monkeypatch):
+    """save_model / find_latest_checkpoint / load_checkpoint (general.py:97-172): file naming, dictionary keys, resume."""
+    import lcasr_amd.optim as OPT
+    import kernel_refs
+    from lcasr_amd.utils.general import save_model, load_checkpoint, find_latest_checkpoint
+    from lcasr_amd.utils.scheduling import SequenceWarmupManager, CosineLRScheduler
+    monkeypatch.setattr(OPT, 'ops', kernel_refs)
+    fx = load_golden('tiny_ln_ragged')
+    m = build_from_fixture(fx)
+    opt = OPT.MADGRAD(m.parameters(), lr=3e-3)
+    run_step(m, fx); opt.step(max_norm=0.8)
+    sch = CosineLRScheduler(opt, warmup_steps=5, peak_value=3e-3, final_value=0.0); sch.step()
+    swm = SequenceWarmupManager(increase_every=5, stop_after=20, start_after=0, initial_sequence_length=512, initial_batch_size=8, max_sequence_length=2048)
+    swm.step(3)
+    cfg = {'checkpointing': {'dir': str(tmp_path)}, 'model': {'n_layers': 2}}
+    for step in (7, 120, 13):
+        save_model(m, opt, sch, step, cfg, sequence_scheduler=swm, seen_ids=[1, 2, 3], epoch=1)
+    assert find_latest_checkpoint(str(tmp_path)) == 'step_120.pt'
+    raw = torch.load(tmp_path / 'step_120.pt', weights_only=True)
+    assert sorted(raw.keys()) == ['config', 'epoch', 'model', 'optimizer', 'podcast_step', 'scheduler', 'seen_ids', 'sequence_scheduler']
+    assert list(raw['model'].keys()) == list(m.state_dict().keys())
+    m2 = build_from_fixture(fx)
+    with torch.no_grad():
+        for p in m2.parameters(): p.add_(1.0)
+    opt2 = OPT.MADGRAD(m2.parameters(), lr=1.0)
+    sch2 = CosineLRScheduler(opt2, warmup_steps=5, peak_value=3e-3, final_value=0.0)
+    swm2 = SequenceWarmupManager(increase_every=1, stop_after=1, start_after=0, initial_sequence_length=1, initial_batch_size=1, max_sequence_length=2)
+    seen, step, epoch = load_checkpoint(None, m2, opt2, sch2, swm2, path=str(tmp_path))
+    assert (seen, step, epoch) == ([1, 2, 3], 120, 1)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()): assert torch.equal(a, b), k
+    assert opt2.k == opt.k and torch.equal(opt2.param_groups[0]['_gss'], opt.param_groups[0]['_gss'])
+    assert swm2.state_dict() == swm.state_dict() and sch2.last_epoch == sch.last_epoch
+    assert load_checkpoint(None, m2, path=str(tmp_path / 'nothing_here')) == ([], 0, 0) if (tmp_path / 'nothing_here').mkdir() is None else True

@@ -149,3 +149,39 @@ def test_fetch_logits_batched_windows_and_greedy_on_gpu():
         assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (sl, ov, float(d.max()), float(d.mean()))
         assert float(np.abs(seq - bat).max()) < 2e-3, float(np.abs(seq - bat).max())   # same kernels, other batch size
         assert dec(torch.from_numpy(ref).cuda(), decode=False) == fx[f'greedy.{ci}'].tolist()
+
+
+@pytest.mark.gpu
+def test_train_recording_chunked_ragged_shrinking_batch():
+    """f2: a batch of long recordings of different lengths, chunk by chunk through the HIP path: rows drop out as recordings
+    end, last chunks are ragged (per-sample lengths), the loss normaliser is the constant chunk_size * batch."""
+    from lcasr_amd.train import Trainer
+    from lcasr_amd.utils.dataloading import chunk_spectogram, plan_chunks
+    from oracle import sconformer_ref as O
+    fx = load_golden('tiny_ln_ragged')
+    m = build_from_fixture(fx, 'cuda')
+    sd0 = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    tr = Trainer(m, lr=1e-3, global_batch=3)
+    g = torch.Generator().manual_seed(1)
+    lens = torch.tensor([1000, 530, 256])
+    audio = torch.randn(3, 80, 1000, generator=g)
+    for b, l in enumerate(lens.tolist()): audio[b, :, l:] = 0
+    V = int(fx['cfg.vocab_size'])
+    seen = []
+
+    def targets(ix, c):
+        n = c['audio'].shape[0]
+        tl = ((c['audio_lengths'] // 8) // 4).clamp(min=1)
+        tg = torch.randint(0, V, (n, int(tl.max())), generator=g)
+        seen.append((ix, n, c['audio'].shape[-1], c['audio_lengths'].tolist(), tg, tl))
+        return tg, tl
+
+    losses = tr.train_recording(audio.cuda(), lens.cuda(), 256, 64, lambda ix, c: tuple(t.cuda() for t in targets(ix, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in c.items()})))
+    plan = plan_chunks(chunk_spectogram(audio, 256, 64), lens.clone(), 64)
+    assert [s[1] for s in seen] == [int(p['selection_mask'].sum()) for p in plan] == [3, 3, 2, 1, 1, 1]
+    assert seen[-1][2] == 40 and seen[2][3] == [256, 146]                   # ragged last chunk; ragged lengths inside a chunk
+    assert len(losses) == len(plan) and all(torch.isfinite(l) for l in losses)
+    # first chunk == one oracle step on the same weights / inputs
+    cfg = O.make_config(**golden_cfg(fx))
+    oloss, _, _ = O.train_step_loss(sd0, cfg, audio[:, :, :256], torch.tensor(seen[0][3]), seen[0][4], seen[0][5])
+    assert abs(float(losses[0]) - float(oloss)) / float(oloss) < 3e-3, (float(losses[0]), float(oloss))
