@@ -9,6 +9,7 @@
 // backward), which halves the HBM traffic of the largest activations of the model.  H axis = time,
 // W axis = frequency, exactly as the reference's Conv2d on (B,1,T,F).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -286,22 +287,27 @@ __device__ __forceinline__ void conv0_at(const float* xs, int F, int tt0, int f2
 struct FGeo {                                            // thread -> (channel group, position lane)
     int cg, plane, c0, PL;
     bool active;
-    __device__ __forceinline__ FGeo(int C) {
+    __device__ __forceinline__ FGeo(int C, int nthreads = 256) {
         const int cgs = C / FC;
-        PL = max(1, 256 / cgs);
+        PL = max(1, nthreads / cgs);
         cg = threadIdx.x % cgs; plane = threadIdx.x / cgs; c0 = cg * FC;
         active = plane < PL;
     }
 };
 
 // d1[t4][f4][c] = bd[c] + sum_{i,j} wd[c][i][j] * SiLU(pre0[2t4+i-1][2f4+j-1][c])      (zero padding of the SiLU output)
+// Every stage-0 activation feeds 1, 2 or 4 outputs (2.25 on average), so it is computed ONCE into a rolling 3-row LDS window
+// ([3][F2][C] bf16 - the precision the reference's autocast conv output has) and the depthwise conv reads the window:
+// per time row t4: stage 5 mel columns -> compute stage-0 rows 2t4, 2t4+1 (row 2t4-1 is the previous step's 2t4+1) -> dw.
 template <typename TX>
-__global__ __launch_bounds__(256) void stage01_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+__global__ __launch_bounds__(512) void stage01_fwd_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
                                                           const float* __restrict__ wdg, const float* __restrict__ bdg, bf16* __restrict__ d1,
                                                           int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
-    extern __shared__ float xs[];                        // [7][F]
-    const FGeo g(C);
+    extern __shared__ float xs[];                        // [7][F] mel | [3][F2][C] bf16 stage-0 activations (slot = t2 mod 3)
+    bf16* act = reinterpret_cast<bf16*>(xs + 7 * F);
+    const FGeo g(C, blockDim.x);
     const int b = blockIdx.y;
+    const int rowel = F2 * C;
     float w0[9][FC], b0[FC], wd[9][FC], bd[FC];
 #pragma unroll
     for (int e = 0; e < FC; ++e) {
@@ -313,7 +319,32 @@ __global__ __launch_bounds__(256) void stage01_fwd_kernel(const TX* __restrict__
     const TX* xb = x + (long)b * F * T;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T4, r0 + rows_per_block);
     for (int t4 = r0; t4 < r1; ++t4) {
-        stage_mel<TX, 7>(xb, xs, F, T, 4 * t4 - 3);
+        const bool first = t4 == r0;                           // the window is empty: row 2t4-1 has to be computed as well
+        const int tlo = first ? 2 * t4 - 1 : 2 * t4;            // stage-0 rows tlo .. 2t4+1 are new
+        // mel columns 2*tlo-1 .. 2*(2t4+1)+1  (5, or 7 for the first step: staged in two calls of 5 / 3 columns -> use 7-wide buffer)
+        __syncthreads();                                       // previous dw phase done with the window + mel patch
+        for (int idx = threadIdx.x; idx < 7 * F; idx += blockDim.x) {
+            const int f = idx / 7, tt = idx - f * 7, t = 4 * t4 - 3 + tt;
+            if (tt >= (first ? 0 : 2)) xs[tt * F + f] = (t >= 0 && t < T) ? ld_f(xb + (long)f * T + t) : 0.f;
+        }
+        __syncthreads();
+        if (g.active) {
+            for (int t2 = tlo; t2 <= 2 * t4 + 1; ++t2) {
+                bf16* arow = act + ((t2 + 3) % 3) * rowel;
+                const bool inside = t2 >= 0 && t2 < T2;
+                for (int f2 = g.plane; f2 < F2; f2 += g.PL) {
+                    float a[FC] = {0.f, 0.f, 0.f, 0.f};
+                    if (inside) {
+                        float pre[FC], xin[9];
+                        conv0_at(xs, F, 2 * (t2 - (2 * t4 - 1)), f2, w0, b0, pre, xin);   // mel column of tap a=0: 2t2-1 = (4t4-3) + 2(t2-2t4+1)
+#pragma unroll
+                        for (int e = 0; e < FC; ++e) a[e] = siluf_(pre[e]);
+                    }
+                    store4(arow + f2 * C + g.c0, a);           // rows outside [0,T2) are the conv's zero padding
+                }
+            }
+        }
+        __syncthreads();
         if (!g.active) continue;
         for (int f4 = g.plane; f4 < F4; f4 += g.PL) {
             float acc[FC];
@@ -321,16 +352,14 @@ __global__ __launch_bounds__(256) void stage01_fwd_kernel(const TX* __restrict__
             for (int e = 0; e < FC; ++e) acc[e] = bd[e];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int t2 = 2 * t4 + i - 1;
-                if (t2 < 0 || t2 >= T2) continue;
+                const bf16* arow = act + ((2 * t4 + i - 1 + 3) % 3) * rowel;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const int f2 = 2 * f4 + j - 1;
                     if (f2 < 0 || f2 >= F2) continue;
-                    float pre[FC], xin[9];
-                    conv0_at(xs, F, 2 * i, f2, w0, b0, pre, xin);
+                    float v[FC]; load4(arow + f2 * C + g.c0, v);
 #pragma unroll
-                    for (int e = 0; e < FC; ++e) acc[e] += wd[i * 3 + j][e] * siluf_(pre[e]);
+                    for (int e = 0; e < FC; ++e) acc[e] += wd[i * 3 + j][e] * v[e];
                 }
             }
             store4(d1 + (((long)b * T4 + t4) * F4 + f4) * C + g.c0, acc);
@@ -357,122 +386,94 @@ __device__ __forceinline__ void fused_reduce(const float (&v)[NV][FC], const FGe
         }
 }
 
-// dwd[c][i][j] += sum dd1[t4][f4][c] * SiLU(pre0[2t4+i-1][2f4+j-1][c]);  dbd[c] += sum dd1
-template <typename TX>
-__global__ __launch_bounds__(256) void stage01_bwd_dw_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
-                                                             const bf16* __restrict__ dd1, float* __restrict__ dwd, float* __restrict__ dbd,
-                                                             int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
-    extern __shared__ float xs[];                        // [7][F] then 256 floats of reduction scratch
-    float* red = xs + 7 * F;
-    const FGeo g(C);
-    const int b = blockIdx.y;
-    float w0[9][FC], b0[FC], gw[9][FC], gb[1][FC];
-#pragma unroll
-    for (int e = 0; e < FC; ++e) {
-        const int c = g.active ? g.c0 + e : 0;
-        b0[e] = b0g[c]; gb[0][e] = 0.f;
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; gw[k][e] = 0.f; }
-    }
-    const TX* xb = x + (long)b * F * T;
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(T4, r0 + rows_per_block);
-    for (int t4 = r0; t4 < r1; ++t4) {
-        stage_mel<TX, 7>(xb, xs, F, T, 4 * t4 - 3);
-        if (!g.active) continue;
-        for (int f4 = g.plane; f4 < F4; f4 += g.PL) {
-            float gv[FC]; load4(dd1 + (((long)b * T4 + t4) * F4 + f4) * C + g.c0, gv);
-#pragma unroll
-            for (int e = 0; e < FC; ++e) gb[0][e] += gv[e];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int t2 = 2 * t4 + i - 1;
-                if (t2 < 0 || t2 >= T2) continue;
-#pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int f2 = 2 * f4 + j - 1;
-                    if (f2 < 0 || f2 >= F2) continue;
-                    float pre[FC], xin[9];
-                    conv0_at(xs, F, 2 * i, f2, w0, b0, pre, xin);
-#pragma unroll
-                    for (int e = 0; e < FC; ++e) gw[i * 3 + j][e] += gv[e] * siluf_(pre[e]);
-                }
-            }
-        }
-    }
-    fused_reduce<9>(gw, g, C, red, dwd, 9);
-    fused_reduce<1>(gb, g, C, red, dbd, 1);
-}
-
-// dpre0[t2][f2][c] = SiLU'(pre0) * sum_{(i,j): 2to+i-1=t2, 2fo+j-1=f2} wd[c][i][j] * dd1[to][fo][c]   (never stored)
-// dw0[c][a][b] += sum dpre0 * x[2f2+b-1][2t2+a-1];  db0[c] += sum dpre0
-template <typename TX>
-__global__ __launch_bounds__(256) void stage01_bwd_conv0_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
-                                                                const float* __restrict__ wdg, const bf16* __restrict__ dd1,
-                                                                float* __restrict__ dw0, float* __restrict__ db0,
-                                                                int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
-    extern __shared__ float xs[];                        // [3][F] mel | 256 floats reduction scratch | 2 dd1 rows [2][F4][C] bf16
-    float* red = xs + 3 * F;
+// Both parameter gradients of the fused stage in ONE pass over the conv0 positions (t2, f2) - a walk over the
+// depthwise OUTPUTS would recompute conv0 + the sigmoid 2.25x per position (every stage-0 activation feeds 1, 2 or 4 outputs),
+// and separate kernels for the two convolutions' gradients would each recompute them again (measured: 4.6 ms -> 2.6 ms).  Per position and channel:
+//   pre = conv0(x), sg = sigmoid(pre), s = pre * sg, s' = sg * (1 + pre * (1 - sg))
+//   for the (i, j) with 2to + i - 1 = t2, 2fo + j - 1 = f2:   g = dd1[to][fo];  gs += wd[i][j] * g;  dwd[i][j] += g * s
+//   dp = gs * s';  db0 += dp;  dw0[a][b] += dp * x[2t2 + a - 1][2f2 + b - 1];   dbd += g at the centre tap (counts each g once)
+// RW conv0 rows share one staging step (2 RW + 1 mel columns, RW/2 + 2 dd1 rows in LDS, two barriers).
+template <typename TX, int RW>
+__global__ __launch_bounds__(256) void stage01_bwd_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+                                                          const float* __restrict__ wdg, const bf16* __restrict__ dd1,
+                                                          float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dwd,
+                                                          float* __restrict__ dbd, int F, int T, int C, int T2, int F2, int T4, int F4,
+                                                          int rows_per_block) {
+    constexpr int NT = 2 * RW + 1, NG = RW / 2 + 2;       // mel time-columns / dd1 rows per staging step
+    extern __shared__ float xs[];                        // [NT][F] mel | 256 floats reduction scratch | [NG][F4][C] bf16 dd1 rows
+    float* red = xs + NT * F;
     bf16* grow = reinterpret_cast<bf16*>(red + 256);
     const FGeo g(C);
     const int b = blockIdx.y;
-    float w0[9][FC], b0[FC], wd[9][FC], gw[9][FC], gb[1][FC];
+    float w0[9][FC], b0[FC], wd[9][FC], gw0[9][FC], gwd[9][FC], gb0[1][FC], gbd[1][FC];
 #pragma unroll
     for (int e = 0; e < FC; ++e) {
         const int c = g.active ? g.c0 + e : 0;
-        b0[e] = b0g[c]; gb[0][e] = 0.f;
+        b0[e] = b0g[c]; gb0[0][e] = 0.f; gbd[0][e] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; wd[k][e] = wdg[c * 9 + k]; gw[k][e] = 0.f; }
+        for (int k = 0; k < 9; ++k) { w0[k][e] = w0g[c * 9 + k]; wd[k][e] = wdg[c * 9 + k]; gw0[k][e] = 0.f; gwd[k][e] = 0.f; }
     }
     const TX* xb = x + (long)b * F * T;
     const bf16* gp = dd1 + (long)b * T4 * F4 * C;
     const int rowel = F4 * C;                             // elements of one dd1 row
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T2, r0 + rows_per_block);
-    for (int t2 = r0; t2 < r1; ++t2) {
-        stage_mel<TX, 3>(xb, xs, F, T, 2 * t2 - 1);
-        // the (at most two) dd1 rows this conv0 row feeds: to = (t2 + 1 - i) / 2 for the i of matching parity.
-        // slot 0 <- row floor((t2+1)/2)  [i = 0 (t2 odd) or i = 1 (t2 even)],  slot 1 <- row (t2-1)/2  [i = 2, t2 odd]
-        const int toA = (t2 + 1) >> 1, toB = (t2 - 1) >> 1;
-        for (int idx = threadIdx.x * 8; idx < rowel; idx += 256 * 8) {
-            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-            if (toA < T4) va = *reinterpret_cast<const uint4*>(gp + (long)toA * rowel + idx);
-            if ((t2 & 1) && toB >= 0 && toB < T4) vb = *reinterpret_cast<const uint4*>(gp + (long)toB * rowel + idx);
-            *reinterpret_cast<uint4*>(grow + idx) = va;
-            *reinterpret_cast<uint4*>(grow + rowel + idx) = vb;
+    for (int tb = r0; tb < r1; tb += RW) {
+        stage_mel<TX, NT>(xb, xs, F, T, 2 * tb - 1);
+        const int to0 = (tb - 1) >> 1;                     // first dd1 row any of the rows tb .. tb+RW-1 can feed (may be -1)
+        for (int idx = threadIdx.x * 8; idx < NG * rowel; idx += 256 * 8) {
+            const int slot = idx / rowel, to = to0 + slot;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (to >= 0 && to < T4) v = *reinterpret_cast<const uint4*>(gp + (long)to * rowel + (idx - slot * rowel));
+            *reinterpret_cast<uint4*>(grow + idx) = v;
         }
         __syncthreads();
         if (!g.active) continue;
-        for (int f2 = g.plane; f2 < F2; f2 += g.PL) {
-            float gs[FC] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                const int tt = t2 + 1 - i;                     // = 2*to
-                if (tt < 0 || (tt & 1)) continue;
-                if ((tt >> 1) >= T4) continue;
-                const bf16* grw = grow + ((i == 2) ? rowel : 0);   // i = 0/1 -> slot 0, i = 2 -> slot 1
+        for (int rr = 0; rr < RW; ++rr) {
+            const int t2 = tb + rr;
+            if (t2 >= r1) break;
+            for (int f2 = g.plane; f2 < F2; f2 += g.PL) {
+                float pre[FC], xin[9], sg[FC], sv[FC];
+                conv0_at(xs, F, 2 * rr, f2, w0, b0, pre, xin);
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    const int ff = f2 + 1 - j;
-                    if (ff < 0 || (ff & 1)) continue;
-                    const int fo = ff >> 1;
-                    if (fo >= F4) continue;
-                    float gv[FC]; load4(grw + fo * C + g.c0, gv);
+                for (int e = 0; e < FC; ++e) { sg[e] = sigmoidf_(pre[e]); sv[e] = pre[e] * sg[e]; }
+                float gs[FC] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int e = 0; e < FC; ++e) gs[e] += wd[i * 3 + j][e] * gv[e];
+                for (int i = 0; i < 3; ++i) {
+                    const int tt = t2 + 1 - i;                 // = 2 * to
+                    if (tt < 0 || (tt & 1)) continue;
+                    const int to = tt >> 1;
+                    if (to >= T4) continue;
+                    const bf16* grw = grow + (to - to0) * rowel;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        const int ff = f2 + 1 - j;
+                        if (ff < 0 || (ff & 1)) continue;
+                        const int fo = ff >> 1;
+                        if (fo >= F4) continue;
+                        float gv[FC]; load4(grw + fo * C + g.c0, gv);
+#pragma unroll
+                        for (int e = 0; e < FC; ++e) {
+                            gs[e] += wd[i * 3 + j][e] * gv[e];
+                            gwd[i * 3 + j][e] += gv[e] * sv[e];
+                            if (i == 1 && j == 1) gbd[0][e] += gv[e];
+                        }
+                    }
                 }
-            }
-            float pre[FC], xin[9];
-            conv0_at(xs, F, 0, f2, w0, b0, pre, xin);
 #pragma unroll
-            for (int e = 0; e < FC; ++e) {
-                const float dp = gs[e] * dsiluf_(pre[e]);
-                gb[0][e] += dp;
+                for (int e = 0; e < FC; ++e) {
+                    const float dp = gs[e] * sg[e] * (1.f + pre[e] * (1.f - sg[e]));
+                    gb0[0][e] += dp;
 #pragma unroll
-                for (int k = 0; k < 9; ++k) gw[k][e] += dp * xin[k];
+                    for (int k = 0; k < 9; ++k) gw0[k][e] += dp * xin[k];
+                }
             }
         }
     }
-    fused_reduce<9>(gw, g, C, red, dw0, 9);
-    fused_reduce<1>(gb, g, C, red, db0, 1);
+    fused_reduce<9>(gw0, g, C, red, dw0, 9);
+    fused_reduce<1>(gb0, g, C, red, db0, 1);
+    fused_reduce<9>(gwd, g, C, red, dwd, 9);
+    fused_reduce<1>(gbd, g, C, red, dbd, 1);
 }
 
 struct LaunchGeo { int PL, iters, threads; dim3 grid; };
@@ -569,9 +570,18 @@ SCONF_API int sconf_sub_stage01_fwd(const void* x, int x_dtype, const float* w0,
     SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_fwd: B <= 65535 and F <= 1024");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
     if (B * T4 * F4 == 0) return 0;
-    const int rpb = std::max(1, (int)cdiv((long)T4 * B, 8192));
-    dim3 grid(cdiv(T4, rpb), (unsigned)B), block(256);
-    const size_t sh = (size_t)7 * F * 4;
+    long target = 2048;
+    if (const char* e = getenv("SCONF_SUB_FWD_BLOCKS")) target = atol(e);                       // tuning
+    const int rpb = std::max(1, (int)cdiv((long)T4 * B, target));
+    dim3 grid(cdiv(T4, rpb), (unsigned)B), block(512);           // 8 waves: two workgroups (LDS-limited) fill a CU's 16 wave slots
+    const size_t sh = (size_t)7 * F * 4 + (size_t)3 * F2 * C * 2;
+    SCONF_REQUIRE(sh <= 150 * 1024, "sconf_sub_stage01_fwd: the 3-row activation window (%ld B) does not fit LDS", (long)sh);
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute((const void*)stage01_fwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute((const void*)stage01_fwd_kernel<bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
     if (x_dtype == SCONF_F32) hipLaunchKernelGGL((stage01_fwd_kernel<float>), grid, block, sh, stream, (const float*)x, w0, b0, wd, bd, (bf16*)d1, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb);
     else hipLaunchKernelGGL((stage01_fwd_kernel<bf16>), grid, block, sh, stream, (const bf16*)x, w0, b0, wd, bd, (bf16*)d1, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb);
     SCONF_LAUNCH_OK("sconf_sub_stage01_fwd");
@@ -587,17 +597,17 @@ SCONF_API int sconf_sub_stage01_bwd(const void* dd1, const void* x, int x_dtype,
     SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_bwd: B <= 65535 and F <= 1024");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
     if (B * T4 * F4 == 0) return 0;
-    const int rpb4 = std::max(1, (int)cdiv((long)T4 * B, 1024)), rpb2 = std::max(1, (int)cdiv((long)T2 * B, 1024));
-    dim3 g4(cdiv(T4, rpb4), (unsigned)B), g2(cdiv(T2, rpb2), (unsigned)B), block(256);
-    const size_t sh7 = (size_t)(7 * F + 256) * 4, sh3 = (size_t)(3 * F + 256) * 4 + (size_t)2 * F4 * C * 2;
-    SCONF_REQUIRE(sh3 <= 64 * 1024 && (F4 * C) % 8 == 0, "sconf_sub_stage01_bwd: dd1 rows do not fit LDS");
-    if (x_dtype == SCONF_F32) {
-        hipLaunchKernelGGL((stage01_bwd_dw_kernel<float>), g4, block, sh7, stream, (const float*)x, w0, b0, (const bf16*)dd1, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb4);
-        hipLaunchKernelGGL((stage01_bwd_conv0_kernel<float>), g2, block, sh3, stream, (const float*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2);
-    } else {
-        hipLaunchKernelGGL((stage01_bwd_dw_kernel<bf16>), g4, block, sh7, stream, (const bf16*)x, w0, b0, (const bf16*)dd1, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb4);
-        hipLaunchKernelGGL((stage01_bwd_conv0_kernel<bf16>), g2, block, sh3, stream, (const bf16*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2);
-    }
+    int rw = 4; long target = 512;                             // measured best of {1,2,4} x {256..2048} at config 3
+    if (const char* e = getenv("SCONF_SUB_BWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { rw = a; target = t; } }   // tuning
+    int rpb2 = std::max(1, (int)cdiv((long)T2 * B, target));
+    rpb2 = (rpb2 + rw - 1) / rw * rw;                          // whole staging steps per workgroup
+    dim3 g2(cdiv(T2, rpb2), (unsigned)B), block(256);
+    const size_t sh = (size_t)((2 * rw + 1) * F + 256) * 4 + (size_t)(rw / 2 + 2) * F4 * C * 2;
+    SCONF_REQUIRE(sh <= 64 * 1024 && (F4 * C) % 8 == 0, "sconf_sub_stage01_bwd: dd1 rows do not fit LDS");
+#define LB(TX, RW_) hipLaunchKernelGGL((stage01_bwd_kernel<TX, RW_>), g2, block, sh, stream, (const TX*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2)
+    if (x_dtype == SCONF_F32) { if (rw == 1) LB(float, 1); else if (rw == 4) LB(float, 4); else LB(float, 2); }
+    else                      { if (rw == 1) LB(bf16, 1); else if (rw == 4) LB(bf16, 4); else LB(bf16, 2); }
+#undef LB
     SCONF_LAUNCH_OK("sconf_sub_stage01_bwd");
     return 0;
 }
