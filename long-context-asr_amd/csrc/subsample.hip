@@ -18,6 +18,9 @@ constexpr int CG8 = 8;                               // channels per thread (16-
 // Thread geometry shared by the conv kernels: a thread OWNS one group of 8 channels for its whole life (its 72 filter
 // taps + bias sit in registers) and walks output positions; a workgroup = cgs channel groups x PL position lanes, so
 // each iteration touches PL x (C*2) contiguous bytes.  blockIdx.y = batch item; all index math is 32-bit.
+template <int W> __device__ __forceinline__ void gemm_free_loadv(const bf16* p, float (&v)[W]) { if constexpr (W == 8) load8(p, v); else load4(p, v); }
+template <int W> __device__ __forceinline__ void gemm_free_storev(bf16* p, const float (&v)[W]) { if constexpr (W == 8) store8(p, v); else store4(p, v); }
+
 struct Geo {
     int cg, plane, c0;
     bool active;
@@ -103,48 +106,81 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const bf16* __restric
     }
 }
 
-// ---- input gradient of the depthwise conv, times SiLU'(pre_in) ------------------------------
-__global__ __launch_bounds__(256) void dwconv2d_bwd_input_kernel(const bf16* __restrict__ dout, const float* __restrict__ w,
-                                                                 const bf16* __restrict__ pre_in, bf16* __restrict__ dpre_in,
-                                                                 int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
-    const Geo g(C, PL);
-    if (!g.active) return;
+// ---- backward of the depthwise conv on SiLU(pre_in): input gradient AND weight / bias gradients in one pass -------------
+// Walks the INPUT positions (ti, fi): each reads its pre-activation once (sigmoid shared by SiLU and SiLU'), gathers the 1, 2
+// or 4 output gradients it feeds, writes dpre_in = SiLU'(pre) * sum w * g, and accumulates dw[i][j] += g * SiLU(pre) per
+// (i, j) in registers (dbias += g at the centre tap, which visits every output exactly once).  Workgroup reduction over the
+// position lanes through LDS, then one atomic per sum.
+template <int CW>
+__global__ __launch_bounds__(256) void dwconv2d_bwd_kernel(const bf16* __restrict__ dout, const float* __restrict__ w,
+                                                           const bf16* __restrict__ pre_in, bf16* __restrict__ dpre_in,
+                                                           float* __restrict__ dw, float* __restrict__ dbias,
+                                                           int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
+    __shared__ float red[256];
+    const int cgs = C / CW;
+    struct { int cg, plane, c0; bool active; } g;
+    g.cg = threadIdx.x % cgs; g.plane = threadIdx.x / cgs; g.c0 = g.cg * CW; g.active = g.plane < PL;
     const int b = blockIdx.y, npos = Ti * Fi;
-    float wk[9][8];
+    float wk[9][CW], gw[9][CW], gbs[CW];
 #pragma unroll
-    for (int e = 0; e < 8; ++e)
+    for (int e = 0; e < CW; ++e) {
+        gbs[e] = 0.f;
 #pragma unroll
-        for (int k = 0; k < 9; ++k) wk[k][e] = w[(g.c0 + e) * 9 + k];
+        for (int k = 0; k < 9; ++k) { wk[k][e] = g.active ? w[(g.c0 + e) * 9 + k] : 0.f; gw[k][e] = 0.f; }
+    }
     const bf16* gb = dout + (long)b * To * Fo * C + g.c0;
     const bf16* pb = pre_in + (long)b * npos * C + g.c0;
     bf16* ob = dpre_in + (long)b * npos * C + g.c0;
-    for (int it = 0; it < iters; ++it) {
-        const int p = (blockIdx.x * iters + it) * PL + g.plane;
-        if (p >= npos) break;
-        const int ti = p / Fi, fi = p - ti * Fi;
-        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (g.active) {
+        for (int it = 0; it < iters; ++it) {
+            const int p = (blockIdx.x * iters + it) * PL + g.plane;
+            if (p >= npos) break;
+            const int ti = p / Fi, fi = p - ti * Fi;
+            float pv[CW], sg[CW], sv[CW]; gemm_free_loadv<CW>(pb + (long)p * C, pv);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int tt = ti + 1 - i;                         // = 2*to
-            if (tt < 0 || (tt & 1)) continue;
-            const int to = tt >> 1;
-            if (to >= To) continue;
+            for (int e = 0; e < CW; ++e) { sg[e] = sigmoidf_(pv[e]); sv[e] = pv[e] * sg[e]; }
+            float acc[CW];
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const int ff = fi + 1 - j;
-                if (ff < 0 || (ff & 1)) continue;
-                const int fo = ff >> 1;
-                if (fo >= Fo) continue;
-                float gv[8]; load8(gb + ((long)to * Fo + fo) * C, gv);
+            for (int e = 0; e < CW; ++e) acc[e] = 0.f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) acc[e] += wk[i * 3 + j][e] * gv[e];
+            for (int i = 0; i < 3; ++i) {
+                const int tt = ti + 1 - i;                         // = 2*to
+                if (tt < 0 || (tt & 1)) continue;
+                const int to = tt >> 1;
+                if (to >= To) continue;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const int ff = fi + 1 - j;
+                    if (ff < 0 || (ff & 1)) continue;
+                    const int fo = ff >> 1;
+                    if (fo >= Fo) continue;
+                    float gv[CW]; gemm_free_loadv<CW>(gb + ((long)to * Fo + fo) * C, gv);
+#pragma unroll
+                    for (int e = 0; e < CW; ++e) {
+                        acc[e] += wk[i * 3 + j][e] * gv[e];
+                        gw[i * 3 + j][e] += gv[e] * sv[e];
+                        if (i == 1 && j == 1) gbs[e] += gv[e];
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < CW; ++e) acc[e] *= sg[e] * (1.f + pv[e] * (1.f - sg[e]));
+            gemm_free_storev<CW>(ob + (long)p * C, acc);
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 10; ++k)
+#pragma unroll
+        for (int e = 0; e < CW; ++e) {
+            __syncthreads();
+            red[threadIdx.x] = g.active ? (k < 9 ? gw[k][e] : gbs[e]) : 0.f;
+            __syncthreads();
+            if (g.plane == 0) {
+                float v = 0.f;
+                for (int pl = 0; pl < PL; ++pl) v += red[pl * cgs + g.cg];
+                if (k < 9) atomicAdd(dw + (g.c0 + e) * 9 + k, v); else atomicAdd(dbias + g.c0 + e, v);
             }
         }
-        float pv[8]; load8(pb + (long)p * C, pv);
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] *= dsiluf_(pv[e]);
-        store8(ob + (long)p * C, acc);
-    }
 }
 
 // ---- weight / bias gradients of a 3x3 stride-2 conv whose output gradient is channels-last -----
@@ -526,10 +562,16 @@ SCONF_API int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void*
     SUB_REQ("sconf_sub_dwconv_bwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
     if (B * Ti * Fi == 0) return 0;
-    const LaunchGeo gi = geo_for(C, B, (long)Ti * Fi, 16384);
-    hipLaunchKernelGGL(dwconv2d_bwd_input_kernel, gi.grid, dim3(gi.threads), 0, stream, (const bf16*)dout, w, (const bf16*)pre_in, (bf16*)dpre_in, (int)Ti, (int)Fi, (int)C, To, Fo, gi.PL, gi.iters);
-    const LaunchGeo gw = geo_for(C, B, (long)To * Fo, 1024);
-    hipLaunchKernelGGL((conv3x3s2_bwd_weight_kernel<true, float>), gw.grid, dim3(gw.threads), 0, stream, (const bf16*)dout, pre_in, dw, dbias, (int)Ti, (int)Fi, (int)C, To, Fo, gw.PL, gw.iters);
+    long target = 1024; int cw = 4;                            // few workgroups: each ends with 10 x CW x C/CW atomics
+    if (const char* e = getenv("SCONF_SUB_DWBWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { cw = a; target = t; } }   // tuning
+    const int cgs = (int)(C / cw);
+    SCONF_REQUIRE(cgs <= 256, "sconf_sub_dwconv_bwd: C too large");
+    const int PL = std::max(1, 256 / cgs), threads = (cgs * PL + 63) / 64 * 64;
+    const long npos = (long)Ti * Fi, per_b = std::max<long>(1, target / B);
+    const int iters = (int)std::max<long>(1, cdiv(npos, (long)PL * per_b));
+    dim3 grid(cdiv(npos, (long)PL * iters), (unsigned)B);
+    if (cw == 8) hipLaunchKernelGGL((dwconv2d_bwd_kernel<8>), grid, dim3(threads), 0, stream, (const bf16*)dout, w, (const bf16*)pre_in, (bf16*)dpre_in, dw, dbias, (int)Ti, (int)Fi, (int)C, To, Fo, PL, iters);
+    else         hipLaunchKernelGGL((dwconv2d_bwd_kernel<4>), grid, dim3(threads), 0, stream, (const bf16*)dout, w, (const bf16*)pre_in, (bf16*)dpre_in, dw, dbias, (int)Ti, (int)Fi, (int)C, To, Fo, PL, iters);
     SCONF_LAUNCH_OK("sconf_sub_dwconv_bwd");
     return 0;
 }

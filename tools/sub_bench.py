@@ -23,3 +23,11 @@ g = [torch.zeros(C, 9, device='cuda'), torch.zeros(C, device='cuda'), torch.zero
 for cfg in sys.argv[1:] or ['2,1024']:
     os.environ['SCONF_SUB_BWD_CFG'] = cfg
     print(f'bwd cfg {cfg:10s}: {t(lambda: ops.sub_stage01_bwd_(dd1, x, w0, b0, wd, *g)):.3f} ms')
+Ti, Fi = 4096, 20
+pre1 = torch.randn(B, Ti, Fi, C, device='cuda').bfloat16()
+dd2 = torch.randn(B, Ti // 2, Fi // 2, C, device='cuda').bfloat16()
+gw, gbv = torch.zeros(C, 9, device='cuda'), torch.zeros(C, device='cuda')
+print(f'dwconv fwd: {t(lambda: ops.sub_dwconv_fwd(pre1, wd, bd)):.3f} ms')
+for cfg in ('8,512', '4,256', '4,512', '4,1024', '4,2048', '4,4096'):
+    os.environ['SCONF_SUB_DWBWD_CFG'] = cfg
+    print(f'dwconv bwd cfg {cfg}: {t(lambda: ops.sub_dwconv_bwd(dd2, wd, pre1, gw, gbv)):.3f} ms')
