@@ -641,10 +641,12 @@ SCONF_API int sconf_sub_stage01_bwd(const void* dd1, const void* x, int x_dtype,
     if (B * T4 * F4 == 0) return 0;
     int rw = 4; long target = 512;                             // measured best of {1,2,4} x {256..2048} at config 3
     if (const char* e = getenv("SCONF_SUB_BWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { rw = a; target = t; } }   // tuning
+    auto lds_bytes = [&](int r) { return (size_t)((2 * r + 1) * F + 256) * 4 + (size_t)(r / 2 + 2) * F4 * C * 2; };
+    while (rw > 1 && lds_bytes(rw) > 64 * 1024) rw /= 2;       // wide stages (C = 512): fewer dd1 rows per staging step
     int rpb2 = std::max(1, (int)cdiv((long)T2 * B, target));
     rpb2 = (rpb2 + rw - 1) / rw * rw;                          // whole staging steps per workgroup
     dim3 g2(cdiv(T2, rpb2), (unsigned)B), block(256);
-    const size_t sh = (size_t)((2 * rw + 1) * F + 256) * 4 + (size_t)(rw / 2 + 2) * F4 * C * 2;
+    const size_t sh = lds_bytes(rw);
     SCONF_REQUIRE(sh <= 64 * 1024 && (F4 * C) % 8 == 0, "sconf_sub_stage01_bwd: dd1 rows do not fit LDS");
 #define LB(TX, RW_) hipLaunchKernelGGL((stage01_bwd_kernel<TX, RW_>), g2, block, sh, stream, (const TX*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb2)
     if (x_dtype == SCONF_F32) { if (rw == 1) LB(float, 1); else if (rw == 4) LB(float, 4); else LB(float, 2); }
