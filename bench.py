@@ -41,7 +41,7 @@ PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 M
 
 
 GEMM_KERNELS = {0: 'gemm_kernel<NT> (128x128 tile)', 1: 'gemm256_kernel<false, 2> (NT, 256x256 tile)',
-                2: 'gemm256_kernel<false, 1> (NT, 256x192 tile)', 3: 'gemm256_kernel<true, 2> (TN, 256x256 tile)'}
+                2: 'gemm192_kernel (NT, 256x192 tile, 3 phases per K-tile)', 3: 'gemm256_kernel<true, 2> (TN, 256x256 tile)'}
 
 
 class GemmTimer:

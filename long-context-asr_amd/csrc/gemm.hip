@@ -369,7 +369,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
 
 // Which kernel sconf_gemm_bf16 runs for a problem (diagnostics / benchmark bookkeeping; same decision code as the launch):
 // 0 = gemm_kernel (128x128 tile, 4 waves), 1 = gemm256_kernel<NT, 256 wide>, 2 = gemm256_kernel<NT, 192 wide>,
-// 3 = gemm256_kernel<TN>.
+// 3 = gemm256_kernel<TN>.  (2 is gemm192_kernel unless SCONF_GEMM_192_4PHASE asks for the 4-phase template.)
 SCONF_API int sconf_gemm_variant(int layout, int64_t M, int64_t N, int64_t K, int64_t lda, int64_t ldb, int split_k, int act,
                                  int has_resid, int has_pre) {
     if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0 || split_k < 1) return -1;

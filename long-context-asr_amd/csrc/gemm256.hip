@@ -389,6 +389,144 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     VMCNT(0);
 }
 
+// ---- 256x192 tile, NT, THREE phases per K-tile -------------------------------------------------------------------------
+// The 4-phase schedule above on a 192-wide tile has MFMA clusters of 16 / 8 / 8 / 16 (the hi column half is one 16-wide
+// tile per wave), so in the two short phases the other wave row's load section outlasts the MFMAs.  With both A quadrants
+// resident (32 more VGPRs; the 192-wide tile has 32 fewer accumulators) the K-tile folds into three 16-MFMA phases:
+//   P0  read B-lo, A-lo     issue A1, B1 of K-tile s+1    MFMA  A-lo x B-lo
+//   P1  read B-hi, A-hi     -                             MFMA  A-lo x B-hi, A-hi x B-hi
+//   P2  -                   issue A0, B0 of K-tile s+2    MFMA  A-hi x B-lo
+// WAR: A0/B0 are read in P0 and restaged in P2 of the same K-tile, A1/B1 are read in P1 and restaged in P0 of the next one -
+// two phases after the read, as above.  RAW: 7 DMA instructions per wave and K-tile (2 + 2 + 2 + 1); the wait at the end of
+// a phase leaves the 7 youngest in flight, which retires A0/B0(s+2) at the end of P2(s+1) and A1/B1(s+2) at the end of
+// P0(s+2) - each one phase (and one barrier, two for the lagging wave row's partner) before its first read.
+__global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
+    constexpr int JH = 1, WC = 48, TN = 192;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A0 | A1 | B0 | B1], the ONLY LDS object
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    Sched sc;
+    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits;
+    if ((int)blockIdx.x >= sc.total) return;
+
+    DmaOffs<false, false, JH> oa; DmaOffs<false, true, JH> ob;
+    oa.set(p.lda, tid); ob.set(p.ldb, tid);
+    auto issue_a = [&](const Cursor& c, int h) {
+        if (!c.valid) return;
+        const long k0 = c.it.kbeg + c.kt * TK;
+        dma_half<2>(reinterpret_cast<const char*>(p.A) + ((long)c.it.m0 * p.lda + k0) * 2, oa.off[h], smem + c.par * BUF + h * HT, tid);
+    };
+    auto issue_b = [&](const Cursor& c, int h) {
+        if (!c.valid) return;
+        const long k0 = c.it.kbeg + c.kt * TK;
+        const char* base = reinterpret_cast<const char*>(p.B) + ((long)c.it.n0 * p.ldb + k0) * 2;
+        if (h == 0) dma_half<2>(base, ob.off[0], smem + c.par * BUF + 2 * HT, tid);
+        else        dma_half<1>(base, ob.off[1], smem + c.par * BUF + 3 * HT, tid);
+    };
+
+    f32x4 acc[2][4][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    Cursor pc;                                        // prefetch cursor: the K-tile whose A0/B0 were issued last
+    pc.v = blockIdx.x; pc.kt = 0; pc.par = 0; pc.valid = true; pc.it = item_coords(p, sc, pc.v);
+    int cv = pc.v; Item cit = pc.it;
+    // prologue: K-tile 0 entirely, A0/B0 of K-tile 1
+    issue_a(pc, 0); issue_b(pc, 0); issue_a(pc, 1); issue_b(pc, 1);
+    pc.advance(p, sc);
+    issue_a(pc, 0); issue_b(pc, 0);
+    if (pc.valid) VMCNT(7); else VMCNT(3);           // A0, B0 of K-tile 0 have landed
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    bf16x8 flo[4][2], fhi[4][2], blo[2][2], bhi[2];
+    while (true) {
+        if (wr) __builtin_amdgcn_s_barrier();         // stagger the second wave row by one barrier
+        for (int kt = 0; kt < cit.nkt; ++kt) {
+            const char* buf = smem + cur * BUF;
+            const bool last = kt == cit.nkt - 1;
+            // ---- P0 ------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) blo[j][kk] = frag_b<false, false>(buf + 2 * HT, wc, j, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) flo[i][kk] = frag_a<false>(buf, wr, i, kk, lane);
+            issue_a(pc, 1); issue_b(pc, 1);             // pc = K-tile s+1
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], flo[i][kk], acc[0][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- P1 ------------------------------------------------------------------------------------------------
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) bhi[kk] = frag_b<false, true>(buf + 3 * HT, wc, 0, kk, lane);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) fhi[i][kk] = frag_a<false>(buf + HT, wr, i, kk, lane);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    acc[0][i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[kk], flo[i][kk], acc[0][i][2], 0, 0, 0);
+                    acc[1][i][2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[kk], fhi[i][kk], acc[1][i][2], 0, 0, 0);
+                }
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+            // ---- P2 ------------------------------------------------------------------------------------------------
+            pc.advance(p, sc);                          // pc = K-tile s+2
+            issue_a(pc, 0); issue_b(pc, 0);
+            wait_window<JH>(pc.valid);
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], fhi[i][kk], acc[1][i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            if (!(wr && last)) __builtin_amdgcn_s_barrier();   // the lagging row goes straight into its epilogue
+            cur ^= 1;
+        }
+        if ((p.debug & 3) != 2 || acc[0][0][0][0] == 1.2345e-30f) {
+            if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
+            else if (p.act == SCONF_ACT_MULAUX) epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
+            else if (p.resid)                   epilogue256<SCONF_ACT_NONE, true, false, JH>(p, acc, cit, wr, wc, lane);
+            else                                epilogue256<SCONF_ACT_NONE, false, false, JH>(p, acc, cit, wr, wc, lane);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_barrier();                 // re-align the two wave rows
+        cv += gridDim.x;
+        if (cv >= sc.total) break;
+        cit = item_coords(p, sc, cv);
+    }
+    VMCNT(0);
+}
+
 }  // namespace
 
 // Tile width for the NT layout: fewest "rounds x width" over the CUs (ties -> the wider tile); 0 = not eligible.
@@ -437,6 +575,7 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
     const int cus = num_cus_cached();
@@ -445,7 +584,8 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
     dim3 grid(std::min(total, cus)), block(512);
     if (layout == 2)   hipLaunchKernelGGL((gemm256_kernel<true, 2>), grid, block, shmem, stream, p);
     else if (w == 256) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, shmem, stream, p);
-    else               hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);
+    else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
+    else               hipLaunchKernelGGL(gemm192_kernel, grid, block, shmem, stream, p);
     SCONF_LAUNCH_OK("sconf_gemm_bf16 (256-row tile)");
     return 0;
 }

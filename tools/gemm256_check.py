@@ -63,20 +63,21 @@ def bench():
               ('tn', 3072, 768, M, 'ff1 wgrad'), ('tn', 768, 3072, M, 'ff2 wgrad'), ('tn', 4096, 768, M, 'vocab wgrad'),
               ('tn', 768, 768, M, 'out wgrad'), ('tn', 2304, 768, M, 'qkv wgrad'),
               ('nt', 4096, 4096, 4096, '4096^3'), ('nt', 8192, 8192, 8192, '8192^3')]
-    agg = {'new': [0.0, 0.0], 'old': [0.0, 0.0], 'w192': [0.0, 0.0], 'auto': [0.0, 0.0]}
+    agg = {'new': [0.0, 0.0], 'old': [0.0, 0.0], 'w192': [0.0, 0.0], 'w192p4': [0.0, 0.0], 'auto': [0.0, 0.0]}
     for layout, m, n, k, label in shapes:
         if layout == 'nt':
             a = torch.randn(m, k, device='cuda').bfloat16(); b = torch.randn(n, k, device='cuda').bfloat16()
         else:
             a = torch.randn(k, m, device='cuda').bfloat16(); b = torch.randn(k, n, device='cuda').bfloat16()
         res = {}
-        for which in ('new', 'old', 'w192', 'auto'):
-            os.environ.pop('SCONF_GEMM_NO_256', None); os.environ.pop('SCONF_GEMM_256_WIDTH', None)
+        for which in ('new', 'old', 'w192', 'w192p4', 'auto'):
+            os.environ.pop('SCONF_GEMM_NO_256', None); os.environ.pop('SCONF_GEMM_256_WIDTH', None); os.environ.pop('SCONF_GEMM_192_4PHASE', None)
             if which == 'old': os.environ['SCONF_GEMM_NO_256'] = '1'
             elif which == 'new': os.environ['SCONF_GEMM_256_WIDTH'] = '256'
-            elif which == 'w192':
+            elif which in ('w192', 'w192p4'):
                 if layout != 'nt' or n % 192: res[which] = (float('nan'), 0); continue
                 os.environ['SCONF_GEMM_256_WIDTH'] = '192'
+                if which == 'w192p4': os.environ['SCONF_GEMM_192_4PHASE'] = '1'
             kw = {}
             if layout == 'tn':
                 kw = dict(out_dtype=torch.float32)
@@ -91,12 +92,12 @@ def bench():
                 e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1) / 10)
             res[which] = (best, kw.get('split_k', 1))
-            if not label.endswith('^3') and which != 'w192':
+            if not label.endswith('^3') and which not in ('w192', 'w192p4'):
                 agg[which][0] += 2.0 * m * n * k; agg[which][1] += best
-        os.environ.pop('SCONF_GEMM_NO_256', None); os.environ.pop('SCONF_GEMM_256_WIDTH', None)
+        os.environ.pop('SCONF_GEMM_NO_256', None); os.environ.pop('SCONF_GEMM_256_WIDTH', None); os.environ.pop('SCONF_GEMM_192_4PHASE', None)
         fl = 2.0 * m * n * k
         print(f'{label:12s} {layout} m={m:6d} n={n:5d} k={k:6d}  256: {res["new"][0]*1e3:7.1f} us {fl/res["new"][0]/1e9:6.0f} TF (split {res["new"][1]:2d})  '
-              f'192: {res["w192"][0]*1e3:7.1f} us {fl/res["w192"][0]/1e9:6.0f} TF  auto: {fl/res["auto"][0]/1e9:6.0f} TF  '
+              f'192: {res["w192"][0]*1e3:7.1f} us {fl/res["w192"][0]/1e9:6.0f} TF (4-phase {fl/res["w192p4"][0]/1e9:6.0f})  auto: {fl/res["auto"][0]/1e9:6.0f} TF  '
               f'128: {res["old"][0]*1e3:7.1f} us {fl/res["old"][0]/1e9:6.0f} TF (split {res["old"][1]:2d})', flush=True)
     for w in ('new', 'old', 'auto'): print(f'aggregate {w}: {agg[w][0]/agg[w][1]/1e9:7.1f} TF/s')
 
