@@ -332,7 +332,7 @@ def test_subsample_ops(ops, B, T, C):
 
 # ------------------------------------------------------------------------------------------------ CTC
 @pytest.mark.parametrize('B,N,C,S,ragged', [(2, 32, 128, 8, False), (3, 125, 128, 31, True), (2, 256, 4096, 64, False),
-                                             (2, 300, 4096, 140, True)])
+                                             (2, 300, 4096, 140, True), (2, 700, 128, 300, True), (1, 2100, 128, 1030, False)])
 def test_ctc(ops, B, N, C, S, ragged):
     g = torch.Generator().manual_seed(N)
     lp = torch.log_softmax(torch.randn(B, N, C, generator=g), -1)
@@ -347,7 +347,7 @@ def test_ctc(ops, B, N, C, S, ragged):
     go = torch.tensor([1.0, 0.5, 2.0][:B])
     grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1)
     gradr = R.ctc_bwd(lp, None, nllr, tg, il, tl, go, C - 1)
-    close(grad, gradr, name='ctc grad', tol=2e-3)
+    close(grad, gradr, name='ctc grad', tol=2e-3 if N < 1000 else 5e-3)       # f32 log-space drift grows with |alpha| ~ 8 N
     assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
 
 
