@@ -10,13 +10,17 @@
 //   3. grad     one workgroup per (b,t) row: occupancy scattered into an LDS histogram over classes, then
 //               grad = g * (exp(lp) - occupancy)   [ATen convention; zero for t >= input_length].
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
+// log(e^a + e^b + e^c): the largest term contributes exactly 1, so only the median and the minimum need an exponential
+// (v_max3 / v_med3 / v_min3 pick them without branches) - 2 exp + 1 log on the serial chain instead of 3 + 1.
 __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float m = fmaxf(a, fmaxf(b, c));
     if (m == -INFINITY) return -INFINITY;
-    return m + __logf(__expf(a - m) + __expf(b - m) + __expf(c - m));
+    const float md = __builtin_amdgcn_fmed3f(a, b, c), mn = fminf(a, fminf(b, c));
+    return m + __logf(1.f + __expf(md - m) + __expf(mn - m));
 }
 
 __global__ void ctc_gather_kernel(const float* __restrict__ lp, const int* __restrict__ targets, const int* __restrict__ in_len,
@@ -165,7 +169,8 @@ SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, cons
     const long total = B * N * Lmax;
     hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, stream,
                        log_probs, targets, input_lengths, target_lengths, lpg, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
-    const int nt = Lmax <= 256 ? 256 : (Lmax <= 2048 ? 512 : 1024);
+    int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
+    if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
     const size_t sh = (size_t)2 * (Lmax + 2) * sizeof(float);
     SCONF_REQUIRE(spt <= 16, "sconf_ctc_fwd: target too long (%ld labels)", (long)Smax);

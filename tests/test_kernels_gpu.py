@@ -348,7 +348,7 @@ def test_ctc(ops, B, N, C, S, ragged):
     grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1)
     gradr = R.ctc_bwd(lp, None, nllr, tg, il, tl, go, C - 1)
     close(grad, gradr, name='ctc grad', tol=2e-3 if N < 1000 else 5e-3)       # f32 log-space drift grows with |alpha| ~ 8 N
-    assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
+    if B > 1: assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

@@ -1,0 +1,20 @@
+"""Micro-benchmark of the CTC kernels at config 3 (B=16, N=2048 frames, 512 labels, 4096 classes)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import lcasr_amd.hip.ops as ops
+B, N, C, S = 16, 2048, 4096, 512
+lp = torch.log_softmax(torch.randn(B, N, C, device='cuda'), -1)
+tg = torch.randint(0, C - 1, (B, S), device='cuda', dtype=torch.int32)
+il = torch.full((B,), N, device='cuda', dtype=torch.int32); tl = torch.full((B,), S, device='cuda', dtype=torch.int32)
+def t(fn, n=5):
+    for _ in range(2): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n
+for nt in sys.argv[1:] or ['0']:
+    os.environ['SCONF_CTC_THREADS'] = nt
+    nll, ws = ops.ctc_fwd(lp, tg, il, tl, C - 1)
+    print(f'threads {nt}: fwd {t(lambda: ops.ctc_fwd(lp, tg, il, tl, C - 1)):.3f} ms  bwd {t(lambda: ops.ctc_bwd(lp, ws, nll, tg, il, tl, None, C - 1)):.3f} ms  nll[0]={float(nll[0]):.3f}')
