@@ -105,6 +105,63 @@ def test_gemm_split_k(ops):
         close(out, R.gemm(a, b, 'tn', alpha=0.5, out_dtype=F32), name=f'split_k {sk}')
 
 
+def _variant(ops, layout, m, n, k, split=1, act='none', resid=False, pre=False):
+    from lcasr_amd.hip import _lib
+    return _lib.load().sconf_gemm_variant(ops.LAYOUT[layout], m, n, k, k if layout != 'tn' else m, k if layout == 'nt' else n, split,
+                                          ops.ACT[act], int(resid), int(pre))
+
+
+@pytest.mark.parametrize('N,K,variant', [(768, 256, 2), (1024, 192, 1), (768, 768, 2), (2048, 128, 1)])
+def test_gemm_256_row_kernels_nt(ops, N, K, variant, monkeypatch):
+    """The large-projection kernels (gemm256.hip: 256x256 4-phase, 256x192 3-phase) with every epilogue they specialise:
+    must be BIT-IDENTICAL to the 128x128 kernel (same K order per accumulator) and agree with an fp32 product."""
+    M = 16384
+    monkeypatch.delenv('SCONF_GEMM_NO_256', raising=False)
+    assert _variant(ops, 'nt', M, N, K) == variant, 'test shape does not route to the kernel it is meant to cover'
+    g = torch.Generator().manual_seed(N + K)
+    a = (torch.randn(M, K, generator=g) * 0.5).to(BF).cuda(); b = (torch.randn(N, K, generator=g) * 0.2).to(BF).cuda()
+    bias = torch.randn(N, generator=g).cuda(); resid = torch.randn(M, N, generator=g).cuda(); aux = torch.randn(M, N, generator=g).to(BF).cuda()
+    ref = a.float() @ b.float().t()
+    cases = [dict(), dict(bias=bias), dict(bias=bias, act='gelu_dsave', save_pre=True), dict(aux=aux, act='mulaux', alpha=0.5),
+             dict(bias=bias, resid=resid, alpha=0.5, out_dtype=F32), dict(out_dtype=F32), dict(bias=bias, save_pre=True)]
+    for kw in cases:
+        new = ops.gemm(a, b, 'nt', **kw)
+        monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
+        old = ops.gemm(a, b, 'nt', **kw)
+        monkeypatch.delenv('SCONF_GEMM_NO_256')
+        new, old = (new if isinstance(new, tuple) else (new,)), (old if isinstance(old, tuple) else (old,))
+        for x, y in zip(new, old):
+            assert torch.equal(x, y), (list(kw), float((x.float() - y.float()).abs().max()))
+        if not kw:
+            assert float((new[0].float() - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
+        if 'resid' in kw:
+            exp = resid + 0.5 * (ref + bias)
+            assert float((new[0] - exp).abs().max()) <= 2e-3 * float(exp.abs().max())
+    acc = torch.randn(M, N, generator=torch.Generator().manual_seed(1)).cuda(); acc0 = acc.clone()
+    ops.gemm(a, b, 'nt', alpha=2.0, accum=acc)                        # C += alpha A.B in place (direct gradient accumulation)
+    assert float((acc - (acc0 + 2.0 * ref)).abs().max()) <= 2e-3 * float(ref.abs().max()) * 2
+
+
+@pytest.mark.parametrize('M,N,split', [(3072, 768, 7), (768, 768, 28), (2304, 1024, 7)])
+def test_gemm_256_row_kernel_tn_split_k(ops, M, N, split, monkeypatch):
+    """Weight-gradient shape class: TN, split-K slabs, through the 256x256 kernel; bit-identical to the 128x128 kernel."""
+    K = 8192
+    monkeypatch.delenv('SCONF_GEMM_NO_256', raising=False)
+    assert _variant(ops, 'tn', M, N, K, split=split) == 3
+    g = torch.Generator().manual_seed(M + N)
+    a = (torch.randn(K, M, generator=g) * 0.3).to(BF).cuda(); b = (torch.randn(K, N, generator=g) * 0.3).to(BF).cuda()
+    new = ops.gemm(a, b, 'tn', out_dtype=F32, split_k=split, alpha=0.5)
+    monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
+    old = ops.gemm(a, b, 'tn', out_dtype=F32, split_k=split, alpha=0.5)
+    monkeypatch.delenv('SCONF_GEMM_NO_256')
+    assert torch.equal(new, old)
+    ref = 0.5 * (a.float().t() @ b.float())
+    assert float((new - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+    acc = torch.ones(M, N, device='cuda')
+    ops.gemm(a, b, 'tn', split_k=split, alpha=0.5, accum=acc)
+    assert float((acc - 1 - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
+
+
 def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(RuntimeError):
         ops.gemm(dev(rnd(16, 12)), dev(rnd(16, 12, seed=1)), 'nt')      # K % 8 != 0
