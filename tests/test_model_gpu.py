@@ -125,6 +125,32 @@ def test_full_size_properties_c3_shape():
 
 
 @pytest.mark.gpu
+def test_benchmark_shape_step_same_through_both_gemm_kernels(monkeypatch):
+    """BASELINE config 3 at the benchmark's token count (B = 8 x T = 16384 -> 16384 tokens per GEMM, where the 256-row kernels
+    take every projection, dgrad and wgrad): one Trainer step with them (default) and one with the 128x128 kernel forced.  The
+    GEMMs are bit-identical, so loss and updated parameters may differ only by the order of the float atomics elsewhere."""
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    from lcasr_amd.train import Trainer, synthetic_batch
+    res = []
+    for force_old in (False, True):
+        if force_old: monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
+        else: monkeypatch.delenv('SCONF_GEMM_NO_256', raising=False)
+        torch.manual_seed(12345)
+        m = SCConformerXL(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, use_rotary=True, rotary_base_freq=1500000,
+                          decoder_norm=True, self_conditioning=True, default_norm='layer_norm').cuda().train()
+        tr = Trainer(m, lr=3e-3, global_batch=8)
+        batch = synthetic_batch(8, 16384, 4095, seed=3)
+        losses = [float(tr.step(*batch)) for _ in range(2)]
+        res.append((losses, tr.opt.flat[0].data.clone()))
+        del tr, m
+    (l_new, p_new), (l_old, p_old) = res
+    assert all(np.isfinite(l_new)) and abs(l_new[0] - l_old[0]) <= 1e-5 * abs(l_old[0]), (l_new, l_old)
+    assert abs(l_new[1] - l_old[1]) <= 2e-3 * abs(l_old[1]), (l_new, l_old)      # after one optimiser step on each side
+    d = (p_new - p_old).abs()
+    assert float(d.max()) <= 2e-2 and float(d.mean()) <= 1e-4, (float(d.max()), float(d.mean()))
+
+
+@pytest.mark.gpu
 def test_fetch_logits_batched_windows_and_greedy_on_gpu():
     """f3: sliding-window inference through the HIP path vs the reference's fetch_logits output (fixture), batched windows
     vs one-at-a-time, and greedy decoding (HIP argmax) vs the reference decoder's token ids."""
