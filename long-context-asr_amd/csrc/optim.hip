@@ -28,19 +28,38 @@ __global__ __launch_bounds__(256) void madgrad_kernel(float* __restrict__ p, con
         if (!(tot < INFINITY)) return;                         // inf/nan gradients: skip the step (GradScaler semantics)
         if (max_norm > 0.f) coef *= fminf(1.f, max_norm / ((float)tot + 1e-6f));
     }
-    long i = (long)blockIdx.x * 256 + threadIdx.x;
-    const long stride = (long)gridDim.x * 256;
-    for (; i < n; i += stride) {
-        float pv = p[i];
-        float gv = g[i] * coef;
-        if (weight_decay != 0.f) gv += weight_decay * pv;
-        const float q = gss[i] + lamb * gv * gv;
-        const float sv = s[i] + lamb * gv;
-        const float rms = cbrtf(q) + eps;
-        const float z = x0[i] - sv / rms;
-        pv = pv * (1.f - ck) + ck * z;
-        gss[i] = q; s[i] = sv; p[i] = pv;
-        if (shadow) shadow[i] = (bf16)pv;
+    // 4 elements per thread and instruction (16-B loads / stores); the flat buffers are 16-B aligned and padded to 4
+    long i = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    const long stride = (long)gridDim.x * 256 * 4;
+    for (; i + 3 < n; i += stride) {
+        float pv[4], gv[4], qv[4], sv[4], xv[4];
+        load4(p + i, pv); load4(g + i, gv); load4(gss + i, qv); load4(s + i, sv); load4(x0 + i, xv);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float gg = gv[e] * coef;
+            if (weight_decay != 0.f) gg += weight_decay * pv[e];
+            qv[e] += lamb * gg * gg;
+            sv[e] += lamb * gg;
+            const float rms = cbrtf(qv[e]) + eps;
+            const float z = xv[e] - sv[e] / rms;
+            pv[e] = pv[e] * (1.f - ck) + ck * z;
+        }
+        store4(gss + i, qv); store4(s + i, sv); store4(p + i, pv);
+        if (shadow) store4(shadow + i, pv);
+    }
+    if (i < n) {                                               // tail (n % 4 elements), first thread past the vector part only
+        for (long j = i; j < n; ++j) {
+            float pv = p[j];
+            float gv = g[j] * coef;
+            if (weight_decay != 0.f) gv += weight_decay * pv;
+            const float q = gss[j] + lamb * gv * gv;
+            const float sv = s[j] + lamb * gv;
+            const float rms = cbrtf(q) + eps;
+            const float z = x0[j] - sv / rms;
+            pv = pv * (1.f - ck) + ck * z;
+            gss[j] = q; s[j] = sv; p[j] = pv;
+            if (shadow) shadow[j] = (bf16)pv;
+        }
     }
 }
 
@@ -66,7 +85,9 @@ SCONF_API int sconf_madgrad_step(float* p, const float* g, float* grad_sum_sq, f
     if (lr != 0.f) lr = lr + eps;                              // madgrad.py:100-101
     const float ck = 1.f - momentum;
     const float lamb = lr * sqrtf((float)(k + 1));
-    const int blocks = (int)std::min<long>(cdiv(n, 256), 4096);
+    SCONF_REQUIRE((((uintptr_t)p | (uintptr_t)g | (uintptr_t)grad_sum_sq | (uintptr_t)s | (uintptr_t)x0) & 15) == 0 && ((uintptr_t)bf16_shadow & 7) == 0,
+                  "sconf_madgrad_step: buffers must be 16-byte aligned");
+    const int blocks = (int)std::min<long>(cdiv(n, 1024), 4096);
     hipLaunchKernelGGL(madgrad_kernel, dim3(blocks), dim3(256), 0, stream, p, g, grad_sum_sq, s, x0, (bf16*)bf16_shadow, (long)n,
                        sumsq, max_norm, grad_scale, lamb, ck, eps, weight_decay);
     SCONF_LAUNCH_OK("sconf_madgrad_step");
