@@ -323,7 +323,9 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.M = (int)M; p.N = (int)N; p.K = (int)K; p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.bias = bias; p.resid = resid; p.ldr = ldr; p.aux = (const bf16*)aux; p.ldaux = ldaux;
     p.pre = (bf16*)pre; p.ldpre = ldpre; p.alpha = alpha; p.act = act; p.out_f32 = out_f32;
+#ifdef SCONF_GEMM_PROBE
     { const char* d = getenv("SCONF_GEMM_DEBUG"); p.debug = d ? atoi(d) : 0; }
+#endif
     const int nkt = cdiv(K, BK);
     p.k_per_split = cdiv(nkt, split_k) * BK;
     const int splits = cdiv(K, p.k_per_split);

@@ -368,7 +368,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             cur ^= 1;
         }
         // ---- epilogue: both wave rows concurrently; one specialised, contiguous code path per (activation, residual) ------
-        if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f) {
+#ifdef SCONF_GEMM_PROBE
+        if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
+#endif
+        {
             if constexpr (KS) epilogue256<SCONF_ACT_NONE, false, true, JH>(p, acc, cit, wr, wc, lane);
             else if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
             else if (p.act == SCONF_ACT_MULAUX)     epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
@@ -507,7 +510,10 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
             if (!(wr && last)) __builtin_amdgcn_s_barrier();   // the lagging row goes straight into its epilogue
             cur ^= 1;
         }
-        if ((p.debug & 3) != 2 || acc[0][0][0][0] == 1.2345e-30f) {
+#ifdef SCONF_GEMM_PROBE
+        if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
+#endif
+        {
             if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
             else if (p.act == SCONF_ACT_MULAUX) epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
             else if (p.resid)                   epilogue256<SCONF_ACT_NONE, true, false, JH>(p, acc, cit, wr, wc, lane);

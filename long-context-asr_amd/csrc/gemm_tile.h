@@ -19,7 +19,9 @@ struct GemmParams {
     long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
     int k_per_split;                                // multiple of BK
     int splits;
-    int debug;                                      // diagnostics only (SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
+#ifdef SCONF_GEMM_PROBE
+    int debug;                                      // probe builds only (make PROBE=1; SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
+#endif
 };
 
 __device__ __forceinline__ int swz_strided(int k) { return ((k & 3) << 1) | (((k >> 3) & 1) << 3); }
@@ -60,7 +62,11 @@ __device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] += bs[e];
     }
+#ifdef SCONF_GEMM_PROBE
     const bool st = p.debug != 1 || v[0] == 1.2345e-30f;
+#else
+    constexpr bool st = true;
+#endif
     if (act == SCONF_ACT_GELU_DSAVE) {
         float dg[W];
 #pragma unroll

@@ -1,4 +1,5 @@
-"""Diagnostic: what the fused epilogues cost on the model's short-K shapes (SCONF_GEMM_DEBUG: 1 = no stores, 2 = no epilogue)."""
+"""Diagnostic: what the fused epilogues cost on the model's short-K shapes (SCONF_GEMM_DEBUG: 1 = no stores, 2 = no epilogue).
+Needs a probe build of the library:  make -C long-context-asr_amd/csrc clean && make -C long-context-asr_amd/csrc PROBE=1"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
