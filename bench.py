@@ -26,7 +26,11 @@ CONFIGS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
     'c3': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
-                          default_norm='layer_norm', bias_in_ff=False), T=16384, batch=16,
+                          default_norm='layer_norm', bias_in_ff=False), T=16384, batch=64,
+               # per-GPU batch: the reference trains this length with 22 recordings per 80 GB GPU (exp/configs/16_ds.yaml:92,
+               # constant 360 k frames per batch); 64 is the same fill of 288 GB (~60 GB of activations) and the most efficient
+               # size measured here (frames/s at B = 16 / 32 / 64 / 128: 5.00 / 5.30 / 5.50 / 5.59 M; above 64 the largest stage
+               # tensor passes 2^31 elements, so 64 it is)
                name='6L/768D/6H SConformerXL, seq=16384, rotary theta=1.5M'),
     'c2': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
