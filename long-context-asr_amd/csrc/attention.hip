@@ -17,6 +17,7 @@
 //  * Backward = two kernels (dK/dV with keys resident per wave; dQ with queries resident per wave):
 //    no atomics, bitwise reproducible, at the price of recomputing S and dP once more.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -403,6 +404,135 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
 }
 
 // =============================================================================================
+// backward dK/dV, 8-wave form (D = 128): grid (ceil(N/256), H, B), 512 threads; each wave owns 32 keys, the workgroup's 256 V
+// rows live in LDS (64 KiB) and the query side streams in 64-row stages (2 x 32.5 KiB) shared by all 8 waves: half the
+// LDS-DMA bytes per MFMA of the 4-wave kernel and one barrier per 64 MFMAs instead of 32.  One workgroup per CU.
+// =============================================================================================
+template <int D, int ROWS>
+__device__ __forceinline__ void glds_tile512(const bf16* base, long sn, int row0, int nrows_valid, char* lds, int tid) {
+    constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = CHUNKS / 512;
+    static_assert(CHUNKS % 512 == 0, "tile must be whole 512-thread passes");
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + 512 * i;
+        const int row = c / CPR, pos = c % CPR;
+        const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+        const int gr = min(row0 + row, nrows_valid - 1);
+        __builtin_amdgcn_global_load_lds((gptr)(base + (long)gr * sn + (pos ^ swz) * 8), (lptr)(lds + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
+    }
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int QR = 64;                             // query rows per stage
+    constexpr int TB = QR * 2 * D;                     // Q tile / dO tile bytes
+    constexpr int SB = 2 * TB + 512;                   // one stage: Q | dO | lse2[64] | delta[64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 256, k0 = kb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
+    const float* lsep = p.lse + ((long)b * p.H + h) * p.N;
+    const float* delp = p.delta + ((long)b * p.H + h) * p.N;
+    const int key = k0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+
+    bf16x8 kf[D / 16];
+    load_bfrags<D>(kf, kp, p.k_sn, k0, p.N, lane);
+    const LaneOffs<D> L(lane);
+    char* sVt = smem + 2 * SB;
+    glds_tile512<D, 256>(vp, p.v_sn, kb0, p.N, sVt, tid);
+    const char* sVw = sVt + wave * 32 * 2 * D;
+    const bool need_mask = p.win_left >= 0 || p.win_right >= 0 || kb0 + 256 > len;   // uniform per workgroup
+
+    const int q_lo = p.win_right < 0 ? 0 : max(0, kb0 - p.win_right);
+    const int q_hi = min(len, p.win_left < 0 ? len : kb0 + 256 + p.win_left);
+    const int t_lo = q_lo / QR, t_hi = (kb0 < len) ? (q_hi + QR - 1) / QR : t_lo;
+
+    f32x16 dkt[D / 32], dvt[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
+
+    float st_l = 0.f, st_d = 0.f;
+    auto gload_stats = [&](int q0) {
+        if (tid < QR) { const int q = q0 + tid; st_l = (q < len) ? lsep[q] * 1.4426950408889634f : INFINITY; st_d = (q < len) ? delp[q] : 0.f; }
+    };
+    auto lstore_stats = [&](char* s) {
+        if (tid < QR) { reinterpret_cast<float*>(s + 2 * TB)[tid] = st_l; reinterpret_cast<float*>(s + 2 * TB + 256)[tid] = st_d; }
+    };
+    if (t_lo < t_hi) {
+        glds_tile512<D, QR>(qp, p.q_sn, t_lo * QR, p.N, smem, tid); glds_tile512<D, QR>(gp, p.do_sn, t_lo * QR, p.N, smem + TB, tid);
+        gload_stats(t_lo * QR); lstore_stats(smem);
+    }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sQ = smem + cur * SB;
+        const char* sG = sQ + TB;
+        const float* sL = reinterpret_cast<const float*>(sQ + 2 * TB);
+        const float* sD = sL + 64;
+        if (t + 1 < t_hi) {
+            char* dS = smem + (cur ^ 1) * SB;
+            glds_tile512<D, QR>(qp, p.q_sn, (t + 1) * QR, p.N, dS, tid); glds_tile512<D, QR>(gp, p.do_sn, (t + 1) * QR, p.N, dS + TB, tid);
+            gload_stats((t + 1) * QR);
+        }
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {            // two 32-query sub-tiles per stage
+            const int rb = 32 * sub, q0 = t * QR + rb;
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, L, rb, st), kf[st], s, 0, 0, 0);     // S[q][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sG, L, rb, st), frag_row<D>(sVw, L, 0, st), dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 a = *reinterpret_cast<const float4*>(sL + rb + 8 * g + 4 * hh);
+                const float4 b_ = *reinterpret_cast<const float4*>(sD + rb + 8 * g + 4 * hh);
+                const float la[4] = {a.x, a.y, a.z, a.w}, da[4] = {b_.x, b_.y, b_.z, b_.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    bool ok = true;
+                    if (need_mask) {
+                        const int q = q0 + acc_row(r, hh);
+                        ok = key < len;
+                        if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
+                        if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
+                    }
+                    const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - la[e]) : 0.f;   // lse2 = +inf for q >= len -> 0
+                    s[r] = pr;
+                    dp[r] = pr * (dp[r] - da[e]);
+                }
+            }
+            const bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb, db), pb0, dvt[db], 0, 0, 0);
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb + 16, db), pb1, dvt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb, db), db0, dkt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb + 16, db), db1, dkt[db], 0, 0, 0);
+            }
+        }
+        if (t + 1 < t_hi) lstore_stats(smem + (cur ^ 1) * SB);
+        __syncthreads();
+    }
+    if (key < p.N) {
+        store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, hh);
+        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, hh);
+    }
+}
+
+// =============================================================================================
 // backward dQ: grid (ceil(N/128), H, B); each wave owns 32 queries, sweeps 64-key tiles
 // =============================================================================================
 template <int D>
@@ -555,7 +685,15 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
     dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
     if (D == 128) {
         hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, p);
-        hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
+        const char* e8 = getenv("SCONF_ATTN_DKDV8");           // "0" keeps the 4-wave dK/dV kernel (A/B, tests); read per call
+        const bool wide = !(e8 && e8[0] == '0');
+        if (wide && N >= 256) {
+            static bool attr_set = false;
+            const int sh8 = 2 * (2 * 64 * 256 + 512) + 256 * 256;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, sh8); attr_set = true; }
+            hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), sh8, stream, p);
+        } else
+            hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
         hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     } else {
         hipLaunchKernelGGL((attn_delta_kernel<32>), dim3(cdiv(rows * 4, 256)), dim3(256), 0, stream, p);
