@@ -87,6 +87,27 @@ __device__ __forceinline__ void glds_tile(const bf16* base, long sn, int row0, i
     }
 }
 
+// the same for workgroups of NTHR threads (tile = whole passes of the workgroup)
+template <int D, int ROWS, int NTHR>
+__device__ __forceinline__ void glds_tile_n(const bf16* base, long sn, int row0, int nrows_valid, char* lds, int tid) {
+    constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = CHUNKS / NTHR;
+    static_assert(CHUNKS % NTHR == 0, "tile must be whole passes of the workgroup");
+    typedef const __attribute__((address_space(1))) void* gptr;
+    typedef __attribute__((address_space(3))) void* lptr;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + NTHR * i;
+        const int row = c / CPR, pos = c % CPR;
+        const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+        const int gr = min(row0 + row, nrows_valid - 1);
+        __builtin_amdgcn_global_load_lds((gptr)(base + (long)gr * sn + (pos ^ swz) * 8), (lptr)(lds + ((tid & ~63) + NTHR * i) * 16), 16, 0, 0);
+    }
+}
+template <int D, int ROWS>
+__device__ __forceinline__ void glds_tile512(const bf16* base, long sn, int row0, int nrows_valid, char* lds, int tid) {
+    glds_tile_n<D, ROWS, 512>(base, sn, row0, nrows_valid, lds, tid);
+}
+
 // Loop-invariant per-lane LDS byte offsets.  tile_off's swizzle depends only on (row & 3) and ((row >> 2) & 3), so a
 // row base that is a multiple of 16 adds linearly (rbase * 2D) and every fragment read is "lane offset + constant":
 // the address math leaves the inner loops (it was ~8 VALU ops per ds_read, several hundred per MFMA block).
@@ -255,6 +276,116 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+// 8-wave form of the forward (D = 128): 256 queries per workgroup, 128-key stages shared by 8 waves.
+template <int D>
+__global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
+    constexpr int KT = 128;                            // keys per stage, consumed as two 64-key halves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = KT * 2 * D;                     // bytes of one stage tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 256, q0 = qb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const int qi = q0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[D / 16];
+    load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+    const LaneOffs<D> L(lane);
+
+    const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
+    const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 256 + p.win_right);
+    const int t_lo = kv_lo / KT, t_hi = (kv_hi + KT - 1) / KT;
+    const bool windowed = p.win_left >= 0 || p.win_right >= 0;
+
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float m = -INFINITY, l = 0.f;
+
+    if (t_lo < t_hi) { glds_tile_n<D, KT, 512>(kp, p.k_sn, t_lo * KT, p.N, smem, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, t_lo * KT, p.N, smem + TB, tid); }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sK = smem + cur * 2 * TB;
+        const char* sV = sK + TB;
+        if (t + 1 < t_hi) {                                  // next K/V tile streams into the other buffer during this tile
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            glds_tile_n<D, KT, 512>(kp, p.k_sn, (t + 1) * KT, p.N, dK, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, (t + 1) * KT, p.N, dK + TB, tid);
+        }
+        for (int half = 0; half < KT / 64; ++half) {
+        const int kv0 = t * KT + half * 64;
+        if (kv0 >= kv_hi) break;                           // uniform: the second half of the last stage may be past the keys
+        const char* sKh = sK + half * 64 * 2 * D;
+        const char* sVh = sV + half * 64 * 2 * D;
+        f32x16 s[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st)
+                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sKh, L, kt * 32, st), qf[st], s[kt], 0, 0, 0);
+        }
+        if (kv0 + 64 > kv_hi || windowed) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + acc_row(r, hh);
+                    bool ok = key < len;
+                    if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
+                    if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
+                    if (!ok) s[kt][r] = -INFINITY;
+                }
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float mn = fmaxf(m, mx);
+        const float mu = (mn == -INFINITY) ? 0.f : mn;
+        const float alpha = __builtin_amdgcn_exp2f((m - mu) * c);
+        const float mc = mu * c;
+        float rs = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] * c - mc); s[kt][r] = e; rs += e; }
+        l = l * alpha + rs;
+        m = mn;
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        bf16x8 pf[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) { pf[kt][0] = pack8(s[kt], 0); pf[kt][1] = pack8(s[kt], 1); }
+#pragma unroll
+        for (int db = 0; db < D / 32; ++db)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, kt * 32 + 16 * s2, db), pf[kt][s2], o[db], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const float lt = l + __shfl_xor(l, 32, 64);
+    if (qi < p.N) {
+        const bool live = qi < len && lt > 0.f;
+        const float inv = live ? 1.f / lt : 0.f;
+        store_t<D>(o, p.o + b * p.o_sb + (long)qi * p.o_sn + h * p.o_sh, inv, hh);
+        if (hh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.N + qi] = live ? (m * c + __log2f(lt)) * 0.6931471805599453f : INFINITY;
+    }
+}
+
 // delta[b][h][n] = sum_d dO * O
 template <int D>
 __global__ void attn_delta_kernel(const AttnParams p) {
@@ -408,22 +539,6 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
 // rows live in LDS (64 KiB) and the query side streams in 64-row stages (2 x 32.5 KiB) shared by all 8 waves: half the
 // LDS-DMA bytes per MFMA of the 4-wave kernel and one barrier per 64 MFMAs instead of 32.  One workgroup per CU.
 // =============================================================================================
-template <int D, int ROWS>
-__device__ __forceinline__ void glds_tile512(const bf16* base, long sn, int row0, int nrows_valid, char* lds, int tid) {
-    constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = CHUNKS / 512;
-    static_assert(CHUNKS % 512 == 0, "tile must be whole 512-thread passes");
-    typedef const __attribute__((address_space(1))) void* gptr;
-    typedef __attribute__((address_space(3))) void* lptr;
-#pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = tid + 512 * i;
-        const int row = c / CPR, pos = c % CPR;
-        const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
-        const int gr = min(row0 + row, nrows_valid - 1);
-        __builtin_amdgcn_global_load_lds((gptr)(base + (long)gr * sn + (pos ^ swz) * 8), (lptr)(lds + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
-    }
-}
-
 template <int D>
 __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -613,6 +728,86 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
 }
 
+// 8-wave form of the dQ kernel (D = 128): 256 queries per workgroup, 128-key stages shared by 8 waves (see attn_bwd_dkdv8_kernel)
+template <int D>
+__global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
+    constexpr int KT = 128;                            // keys per stage (two 64 KiB stages: one workgroup per CU)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = KT * 2 * D;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 256, q0 = qb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
+    const int qi = q0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+    const float lse2 = (qi < len) ? p.lse[((long)b * p.H + h) * p.N + qi] * 1.4426950408889634f : INFINITY;
+    const float dlt = (qi < len) ? p.delta[((long)b * p.H + h) * p.N + qi] : 0.f;
+
+    bf16x8 qf[D / 16], gf[D / 16];
+    load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+    load_bfrags<D>(gf, gp, p.do_sn, q0, p.N, lane);
+    const LaneOffs<D> L(lane);
+    const bool windowed = p.win_left >= 0 || p.win_right >= 0;
+
+    const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
+    const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 256 + p.win_right);
+    const int t_lo = kv_lo / KT, t_hi = (qb0 < len) ? (kv_hi + KT - 1) / KT : t_lo;
+
+    f32x16 dqt[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
+
+    if (t_lo < t_hi) { glds_tile_n<D, KT, 512>(kp, p.k_sn, t_lo * KT, p.N, smem, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, t_lo * KT, p.N, smem + TB, tid); }
+    __syncthreads();
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sK = smem + cur * 2 * TB;
+        const char* sV = sK + TB;
+        if (t + 1 < t_hi) {
+            char* dK = smem + (cur ^ 1) * 2 * TB;
+            glds_tile_n<D, KT, 512>(kp, p.k_sn, (t + 1) * KT, p.N, dK, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, (t + 1) * KT, p.N, dK + TB, tid);
+        }
+        const int kv0 = t * KT;
+#pragma unroll
+        for (int kt = 0; kt < KT / 32; ++kt) {
+            f32x16 s, dp;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+            for (int st = 0; st < D / 16; ++st) {
+                s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, L, kt * 32, st), qf[st], s, 0, 0, 0);    // S^T[key][q]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, L, kt * 32, st), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
+            }
+            if (!(windowed || kv0 + KT > kv_hi)) {                               // ONE uniform branch, two straight-line bodies
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt);
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kv0 + kt * 32 + acc_row(r, hh);
+                    bool ok = key < len;
+                    if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
+                    if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
+                    dp[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt) : 0.f;
+                }
+            }
+            const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#pragma unroll
+            for (int db = 0; db < D / 32; ++db) {
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32, db), d0, dqt[db], 0, 0, 0);
+                dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32 + 16, db), d1, dqt[db], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+}
+
 void set_lds_attrs() {
     static bool done = false;
     if (done) return;
@@ -651,7 +846,13 @@ SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* 
     p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
     dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
     set_lds_attrs();
-    if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
+    const char* e8 = getenv("SCONF_ATTN_WIDE");            // "0" keeps the 4-wave kernels (A/B, tests); read per call
+    const bool wide = !(e8 && e8[0] == '0') && N >= 256;
+    if (D == 128 && wide) {
+        static bool attr_set = false;
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
+        hipLaunchKernelGGL((attn_fwd8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), 4 * 128 * 256, stream, p);
+    } else if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     else          hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
     SCONF_LAUNCH_OK("sconf_attn_fwd");
     return 0;
@@ -694,7 +895,13 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
             hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), sh8, stream, p);
         } else
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
-        hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
+        const char* eq = getenv("SCONF_ATTN_WIDE");
+        if (!(eq && eq[0] == '0') && N >= 256) {
+            static bool attr_set = false;
+            if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
+            hipLaunchKernelGGL((attn_bwd_dq8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), 4 * 128 * 256, stream, p);
+        } else
+            hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     } else {
         hipLaunchKernelGGL((attn_delta_kernel<32>), dim3(cdiv(rows * 4, 256)), dim3(256), 0, stream, p);
         hipLaunchKernelGGL((attn_bwd_dkdv_kernel<32>), grid, block, 2 * (2 * 32 * 64 + 256) + 128 * 64, stream, p);

@@ -273,12 +273,13 @@ ATT_CASES = [  # B, N, H, D, lengths, window
 @pytest.mark.parametrize('dkdv8', [True, False])
 @pytest.mark.parametrize('case', ATT_CASES)
 def test_attention_fwd_bwd(ops, case, dkdv8, monkeypatch):
-    """dkdv8: the 8-wave dK/dV kernel (default for head_dim 128, N >= 256) vs the 4-wave one (SCONF_ATTN_DKDV8=0)."""
+    """dkdv8: the 8-wave forward / dQ / dK-dV kernels (default for head_dim 128, N >= 256) vs the 4-wave ones
+    (SCONF_ATTN_WIDE=0, SCONF_ATTN_DKDV8=0)."""
     B, N, H, D, lens, win = case
     if not dkdv8:
-        if D != 128 or N < 256: pytest.skip('only the 4-wave kernel exists for this shape')
-        monkeypatch.setenv('SCONF_ATTN_DKDV8', '0')
-    else: monkeypatch.delenv('SCONF_ATTN_DKDV8', raising=False)
+        if D != 128 or N < 256: pytest.skip('only the 4-wave kernels exist for this shape')
+        monkeypatch.setenv('SCONF_ATTN_DKDV8', '0'); monkeypatch.setenv('SCONF_ATTN_WIDE', '0')
+    else: monkeypatch.delenv('SCONF_ATTN_DKDV8', raising=False); monkeypatch.delenv('SCONF_ATTN_WIDE', raising=False)
     q, k, v = rnd(B, N, H, D), rnd(B, N, H, D, seed=1), rnd(B, N, H, D, seed=2)
     ln = torch.tensor(lens, dtype=torch.int32) if lens else None
     o, lse = ops.attn_fwd(dev(q), dev(k), dev(v), dev(ln), win)

@@ -20,3 +20,5 @@ ms = t(lambda: ops.attn_fwd(q, k, v, None))
 print(f'attn fwd  {ms*1e3:8.1f} us  {fl/ms/1e9:7.1f} TF/s (algorithmic 4BHN^2D)')
 ms = t(lambda: ops.attn_bwd(q, k, v, o, do, lse, None))
 print(f'attn bwd  {ms*1e3:8.1f} us  {2.5*fl/ms/1e9:7.1f} TF/s (algorithmic 10BHN^2D; executed 14BHN^2D = {3.5*fl/ms/1e9:7.1f})')
+ms2 = t(lambda: (ops.attn_fwd(q, k, v, None), ops.attn_bwd(q, k, v, o, do, lse, None)))
+print(f'attn fwd+bwd {ms2*1e3:8.1f} us')
