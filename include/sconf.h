@@ -56,8 +56,10 @@ int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* weight, co
 int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d);
 int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                    const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype, float* dweight,
-                   float* dbias, float* workspace, int64_t workspace_floats, int64_t M, int64_t d, float eps,
-                   sconf_stream_t stream);
+                   float* dbias, float* workspace, int64_t workspace_floats, void* dx_bf16, float* dx_colsum,
+                   int64_t M, int64_t d, float eps, sconf_stream_t stream);
+/* dx_bf16 / dx_colsum (both or neither; need f32 dx and the workspace): a bf16 copy of dx and its column sums [d] (overwritten),
+ * for the block that receives dx as its output gradient - its GEMM operand and its output-projection bias gradient. */
 
 int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
 /* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */

@@ -108,15 +108,17 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
                                                        const float* __restrict__ w, const float* __restrict__ stat_mean,
                                                        const float* __restrict__ stat_rstd, const float* __restrict__ dres,
                                                        TO* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
-                                                       float* __restrict__ ws, int M, int d, float eps) {
+                                                       float* __restrict__ ws, bf16* __restrict__ dx16, int M, int d, float eps) {
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * NB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * NB_WAVES;
-    float aw[MAXIT][4], ab[MAXIT][4], wv[MAXIT][4];
+    // dx16 (SLAB only): a bf16 copy of dx for the GEMMs of the block that receives dx as its output gradient, and the column
+    // sums of that copy (that block's output-projection bias gradient) - saves it a cast pass and a column-sum pass over dx.
+    float aw[MAXIT][4], ab[MAXIT][4], wv[MAXIT][4], ac[MAXIT][4];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         const int c = it * 256 + lane * 4;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { aw[it][e] = 0.f; ab[it][e] = 0.f; wv[it][e] = 0.f; }
+        for (int e = 0; e < 4; ++e) { aw[it][e] = 0.f; ab[it][e] = 0.f; wv[it][e] = 0.f; ac[it][e] = 0.f; }
         if (c < d) load4(w + c, wv[it]);
     }
     BwdRow<TI, TG, MAXIT> nxt;
@@ -164,6 +166,11 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = r[e] + rstd * g[it][e] * wv[it][e] - c1 - xh[it][e] * c2;
                 store4(dxr + c, o);
+                if (SLAB && dx16) {
+                    store4(dx16 + (long)row * d + c, o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ac[it][e] += (float)(bf16)o[e];
+                }
             }
         }
     }
@@ -176,11 +183,12 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
         if (it * 256 >= d) break;                                   // uniform
         const int c = it * 256 + lane * 4;
 #pragma unroll
-        for (int pass = 0; pass < 2; ++pass) {
-            if (pass == 1 && !(MODE == 0 && db)) break;             // uniform
+        for (int pass = 0; pass < 3; ++pass) {
+            if (pass == 1 && !(MODE == 0 && db)) continue;          // uniform
+            if (pass == 2 && !(SLAB && dx16)) continue;             // uniform
             __syncthreads();
 #pragma unroll
-            for (int e = 0; e < 4; ++e) red[wvi][lane * 4 + e] = pass == 0 ? aw[it][e] : ab[it][e];
+            for (int e = 0; e < 4; ++e) red[wvi][lane * 4 + e] = pass == 0 ? aw[it][e] : (pass == 1 ? ab[it][e] : ac[it][e]);
             __syncthreads();
             if (wvi == 0 && c < d) {
                 float v[4];
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
 #pragma unroll
                     for (int k = 0; k < NB_WAVES; ++k) v[e] += red[k][lane * 4 + e];
                 }
-                if (SLAB) store4(ws + ((long)blockIdx.x * 2 + pass) * d + c, v);
+                if (SLAB) store4(ws + ((long)blockIdx.x * 3 + pass) * d + c, v);
                 else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) atomicAdd((pass == 0 ? dw : db) + c + e, v[e]);
@@ -213,32 +221,34 @@ int launch_fwd(const void* x, int xdt, const float* w, const float* b, void* y, 
     return 0;
 }
 
-// dw[c] += sum_b ws[b][0][c], db[c] += sum_b ws[b][1][c]: one lane per column, 16 waves stride over the workgroups' slabs
+// dw[c] += sum_b ws[b][0][c], db[c] += sum_b ws[b][1][c], cs[c] = sum_b ws[b][2][c]: one lane per column, 16 waves stride over
+// the workgroups' slabs (fixed summation order)
 __global__ __launch_bounds__(1024) void norm_bwd_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ db,
-                                                               int nblocks, int d) {
+                                                               float* __restrict__ cs, int nblocks, int d) {
     __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int col = blockIdx.x * 64 + lane;                          // in [0, 2d): dw columns then db columns
-    const int pass = col >= d, c = col - pass * d;
+    const int col = blockIdx.x * 64 + lane;                          // in [0, 3d): dw columns, db columns, cs columns
+    const int pass = col / d, c = col - pass * d;
+    float* const outp = pass == 0 ? dw : (pass == 1 ? db : cs);
+    const bool live = col < 3 * d && outp != nullptr;
     float a = 0.f;
-    if (col < 2 * d && (pass == 0 || db)) {
+    if (live) {
         float t[4] = {0.f, 0.f, 0.f, 0.f};
         int b = wv;
         for (; b + 48 < nblocks; b += 64) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) t[u] += ws[((long)(b + 16 * u) * 2 + pass) * d + c];
+            for (int u = 0; u < 4; ++u) t[u] += ws[((long)(b + 16 * u) * 3 + pass) * d + c];
         }
-        for (; b < nblocks; b += 16) t[0] += ws[((long)b * 2 + pass) * d + c];
+        for (; b < nblocks; b += 16) t[0] += ws[((long)b * 3 + pass) * d + c];
         a = (t[0] + t[1]) + (t[2] + t[3]);
     }
     red[wv][lane] = a;
     __syncthreads();
-    if (wv == 0 && col < 2 * d && (pass == 0 || db)) {
+    if (wv == 0 && live) {
         float v = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) v += red[k][lane];
-        float* o = (pass == 0 ? dw : db) + c;
-        *o += v;
+        if (pass == 2) outp[c] = v; else outp[c] += v;
     }
 }
 
@@ -258,11 +268,13 @@ static BwdGeo bwd_geo(int nit) {
 
 template <int MODE, int NIT>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
-               const float* dres, void* dx, int odt, float* dw, float* db, float* ws, long ws_floats, int M, int d, float eps, hipStream_t st) {
+               const float* dres, void* dx, int odt, float* dw, float* db, float* ws, long ws_floats, bf16* dx16, float* dx_colsum,
+               int M, int d, float eps, hipStream_t st) {
     const BwdGeo geo = bwd_geo(NIT);
     dim3 grid(min(cdiv(M, geo.nbw), geo.maxg)), block(64 * geo.nbw);
-    const bool slab = ws && ws_floats >= (long)grid.x * 2 * d;
-#define L4(TI, TG, TO, NBW, AH, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AH, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, M, d, eps)
+    const bool slab = ws && ws_floats >= (long)grid.x * 3 * d;
+    if (!slab) { dx16 = nullptr; dx_colsum = nullptr; }
+#define L4(TI, TG, TO, NBW, AH, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AH, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, dx16, M, d, eps)
 #define L(TI, TG, TO) do { \
     if (geo.nbw == 8) { if (geo.ahead) { if (slab) L4(TI, TG, TO, 8, true, true); else L4(TI, TG, TO, 8, true, false); } \
                         else           { if (slab) L4(TI, TG, TO, 8, false, true); else L4(TI, TG, TO, 8, false, false); } } \
@@ -277,7 +289,8 @@ int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, 
     }
 #undef L
 #undef L4
-    if (slab) hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(cdiv(2 * d, 64)), dim3(1024), 0, st, ws, dw, db, (int)grid.x, d);
+    if (slab) hipLaunchKernelGGL(norm_bwd_reduce_kernel, dim3(cdiv(3 * d, 64)), dim3(1024), 0, st, ws, dw, (MODE == 0 ? db : nullptr),
+                                 dx16 ? dx_colsum : nullptr, (int)grid.x, d);
     return 0;
 }
 
@@ -307,19 +320,20 @@ SCONF_API int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* 
 // into dweight/dbias in a fixed order; without it the workgroups fall back to f32 atomics (slower, order not fixed).
 SCONF_API int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d) {
     const BwdGeo geo = bwd_geo((int)((d + 255) / 256));
-    return (int64_t)min(cdiv(M, geo.nbw), geo.maxg) * 2 * d;
+    return (int64_t)min(cdiv(M, geo.nbw), geo.maxg) * 3 * d;
 }
 SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                              const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype,
                              float* dweight, float* dbias, float* workspace, int64_t workspace_floats,
-                             int64_t M, int64_t d, float eps, hipStream_t stream) {
+                             void* dx_bf16, float* dx_colsum, int64_t M, int64_t d, float eps, hipStream_t stream) {
     SCONF_REQUIRE(mode >= 0 && mode <= 2, "sconf_norm_bwd: bad mode %d", mode);
     SCONF_REQUIRE(d % 4 == 0 && d <= MAXD && d > 0, "sconf_norm_bwd: d=%ld must be a multiple of 4 and <= 2048", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm_bwd: too many rows");
+    SCONF_REQUIRE(!dx_bf16 || (dx_dtype == SCONF_F32 && dx_colsum && workspace), "sconf_norm_bwd: the bf16 twin needs an f32 dx, dx_colsum and a workspace");
     if (M == 0) return 0;
-    if (mode == 0) NIT_DISPATCH(launch_bwd, 0, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
-    else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
-    else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (int)M, (int)d, eps, stream);
+    if (mode == 0) NIT_DISPATCH(launch_bwd, 0, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (bf16*)dx_bf16, dx_colsum, (int)M, (int)d, eps, stream);
+    else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (bf16*)dx_bf16, dx_colsum, (int)M, (int)d, eps, stream);
+    else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (bf16*)dx_bf16, dx_colsum, (int)M, (int)d, eps, stream);
     SCONF_LAUNCH_OK("sconf_norm_bwd");
     return 0;
 }

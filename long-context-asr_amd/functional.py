@@ -49,6 +49,7 @@ def clear_weight_cache() -> None:
 
 def refresh_weight_shadows() -> None:
     """Re-cast all registered shadows from their f32 masters: one launch (sconf_cast_shadows)."""
+    _twins.clear()                                   # gradients parked by a backward nobody consumed
     if not _shadows:
         return
     ents = list(_shadows.values())
@@ -134,6 +135,38 @@ class _G:
         return self.t.view(self.p.shape)
 
 
+# ---- bf16 twins of residual-stream gradients -------------------------------------------------------------------------------
+# A block's backward ends in norm_bwd, which writes dx (f32, the gradient of the residual stream).  The block BEFORE it
+# receives that tensor as dy and starts with dy16 = bf16(dy) and, if its output projection has a bias, colsum(dy16): two
+# more passes over 4 M d bytes.  norm_bwd can produce both in the pass it already makes (ops.norm_bwd(twin=True)); the
+# producer parks them here and the consumer takes them IF dy is that very memory, unmodified (same storage + version counter;
+# the strong reference keeps the storage alive and keeps autograd from accumulating into it in place).  Anything else falls back to cast / colsum.
+_twins: dict = {}
+
+
+def _park_twin(dx: torch.Tensor, dx16: torch.Tensor, colsum: torch.Tensor) -> None:
+    _twins[dx.data_ptr()] = (dx, dx._version, dx16, colsum)       # the entry keeps dx's storage alive: the address cannot be reused
+
+
+def _take_twin(dy: torch.Tensor):
+    """(dy16, colsum or None) for an f32 residual-stream gradient: the parked twin if dy is the parked dx (or a view of all of
+    it - autograd reshapes between blocks; views share the version counter), else a fresh cast."""
+    e = _twins.pop(dy.data_ptr(), None)
+    if e is not None and dy.dtype == F32 and dy.is_contiguous() and dy.numel() == e[0].numel() and dy._version == e[1] \
+            and dy.untyped_storage().data_ptr() == e[0].untyped_storage().data_ptr():
+        return e[2].view(dy.shape), e[3]
+    return ops.cast(dy, BF16), None
+
+
+def _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dres, dnw, dnb):
+    """norm backward of a residual branch: dx = dres + norm'(x) dh (f32), with the bf16 twin parked for the receiving block."""
+    if dres is None:
+        return ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, None, F32, dnw, dnb)
+    dx, dx16, cs = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dres, F32, dnw, dnb, twin=True)
+    _park_twin(dx, dx16, cs)
+    return dx
+
+
 def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, w: torch.Tensor, alpha: float = 1.0):
     """dW[N',K'] (+)= alpha * dy^T x  (TN GEMM, split-K over the token dimension when the tile count is small)."""
     Mtok, Nout = dy16.shape
@@ -146,11 +179,15 @@ def _wgrad(dy16: torch.Tensor, x16: torch.Tensor, w: torch.Tensor, alpha: float 
     return ops.gemm(dy16, x16, 'tn', alpha=alpha, out_dtype=F32, split_k=sk).reshape(w.shape)
 
 
-def _bgrad(dy16: torch.Tensor, bias: Optional[torch.Tensor], alpha: float = 1.0):
+def _bgrad(dy16: torch.Tensor, bias: Optional[torch.Tensor], alpha: float = 1.0, colsum: Optional[torch.Tensor] = None):
+    """bias gradient = alpha * column sums of dy16 (taken from `colsum` when the producer of dy already made them)."""
     if bias is None:
         return None
     g = _G(bias)
-    ops.colsum_(dy16, g.t, alpha)
+    if colsum is not None:
+        g.t.add_(colsum.view(g.t.shape), alpha=alpha)
+    else:
+        ops.colsum_(dy16, g.t, alpha)
     return g.out()
 
 
@@ -210,15 +247,15 @@ class FFBlockFn(Function):
         else:
             h, u, a = t[11:]
         dy = dy.contiguous()
-        dy16 = ops.cast(dy, BF16)
+        dy16, dycs = _take_twin(dy)
         du = ops.gemm(dy16, w2t, 'nt', aux=u, act='mulaux', alpha=scale)           # (M,4d): dy W2 * gelu'(pre)
         dw2 = _wgrad(dy16, a, pw2, alpha=scale)
-        db2 = _bgrad(dy16, pb2, alpha=scale)
+        db2 = _bgrad(dy16, pb2, alpha=scale, colsum=dycs)
         dw1 = _wgrad(du, h, pw1)
         db1 = _bgrad(du, pb1)
         dh = ops.gemm(du, w1t, 'nt')
         dnw, dnb = _G(pnw), _G(pnb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        dx = _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, dnw.t, dnb.t)
         return dx, dnw.out(), dnb.out(), dw1, dw2, db1, db2, None, None, None, None, None
 
 
@@ -254,11 +291,11 @@ class AttnBlockFn(Function):
         pnw, pnb, pwq, pwo, pbq, pbo = ctx.P
         x, nw, nb, mean, rstd, wqt, wot, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
         dy = dy.contiguous()
-        dy16 = ops.cast(dy, BF16)
+        dy16, dycs = _take_twin(dy)
         o2 = o.view(B * N, H * D)
         do = ops.gemm(dy16, wot, 'nt')                                                # (M, H*D)
         dwo = _wgrad(dy16, o2, pwo)
-        dbo = _bgrad(dy16, pbo)
+        dbo = _bgrad(dy16, pbo, colsum=dycs)
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, lengths, window)
         dqkv = ops.rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D)
         dwq = _wgrad(dqkv, h, pwq)
@@ -267,7 +304,7 @@ class AttnBlockFn(Function):
         if lengths is not None:
             ops.mask_rows_(dh, lengths, B, N)
         dnw, dnb = _G(pnw), _G(pnb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        dx = _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, dnw.t, dnb.t)
         return (dx, dnw.out(), dnb.out(), dwq, dwo, dbq, dbo) + (None,) * 11
 
 
@@ -307,17 +344,17 @@ class ConvBlockFn(Function):
         pnw, pnb, pw1, pb1, pwdw, pbdw, pbrnw, pbrnb, pw2, pb2 = ctx.P
         x, nw, nb, mean, rstd, w1t, w2t, bpw1, bpw2, wdw2, brn_w, lengths, h, g, hc, coef, y2 = ctx.saved_tensors
         dy = dy.contiguous()
-        dy16 = ops.cast(dy, BF16)
+        dy16, dycs = _take_twin(dy)
         dy2 = ops.gemm(dy16, w2t, 'nt')                                               # (M, d)
         dw2 = _wgrad(dy16, y2, pw2)
-        db2 = _bgrad(dy16, pb2)
+        db2 = _bgrad(dy16, pb2, colsum=dycs)
         ddw, dbdw, dbrnw, dbrnb = _G(pwdw, wdw2.shape), _G(pbdw), _G(pbrnw), _G(pbrnb)
         dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw.t, dbdw.t, dbrnw.t, dbrnb.t)
         dw1 = _wgrad(dg, h, pw1)
         db1 = _bgrad(dg, pb1)
         dh = ops.gemm(dg, w1t, 'nt')
         dnw, dnb = _G(pnw), _G(pnb)
-        dx = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, F32, dnw.t, dnb.t)
+        dx = _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, dnw.t, dnb.t)
         return (dx, dnw.out(), dnb.out(), dw1, db1, ddw.out(), dbdw.out(), dbrnw.out(), dbrnb.out(), None, None, None, dw2, db2) + (None,) * 7
 
 
@@ -353,17 +390,17 @@ class SelfCondFn(Function):
         pnw, pnb, pwf, pbf, pwr, pbr = ctx.P
         x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p = ctx.saved_tensors
         dy = dy.contiguous()
-        dy16 = ops.cast(dy, BF16)
+        dy16, dycs = _take_twin(dy)
         dp = ops.gemm(dy16, wrt, 'nt')                                                # (M, V+1)
         dwr = _wgrad(dy16, p, pwr)
-        dbr = _bgrad(dy16, pbr)
+        dbr = _bgrad(dy16, pbr, colsum=dycs)
         dl = ops.softmax_bwd(p, dp, False, BF16)
         dwf = _wgrad(dl, hn, pwf)
         dbf = _bgrad(dl, pbf)
         dhn = ops.gemm(dl, wft, 'nt')
         if has_norm:
             dnw, dnb = _G(pnw), _G(pnb)
-            dx = ops.norm_bwd(dhn, x, nw, mean, rstd, mode, eps, dy, F32, dnw.t, dnb.t)
+            dx = _norm_bwd_res(dhn, x, nw, mean, rstd, mode, eps, dy, dnw.t, dnb.t)
             return dx, dnw.out(), dnb.out(), dwf, dbf, dwr, dbr, None, None, None
         dx = dy + ops.cast(dhn, F32)
         return dx, None, None, dwf, dbf, dwr, dbr, None, None, None

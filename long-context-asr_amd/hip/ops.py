@@ -153,17 +153,22 @@ def norm_fwd(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]
 
 def norm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, mode: str,
              eps: float, dres: Optional[torch.Tensor], dx_dtype: torch.dtype, dweight: torch.Tensor,
-             dbias: Optional[torch.Tensor]) -> torch.Tensor:
-    """dx = dres + norm'(x)·dy;  dweight / dbias are accumulated in place (f32)."""
+             dbias: Optional[torch.Tensor], twin: bool = False):
+    """dx = dres + norm'(x)·dy;  dweight / dbias are accumulated in place (f32).
+    twin=True (f32 dx only) also returns (dx16, colsum): a bf16 copy of dx and its column sums (d,) f32, produced in the
+    same pass for the block that receives dx as its output gradient."""
     _chk(dy, 'dy'); _chk(x, 'x'); _chk(dweight, 'dweight', torch.float32)
     d = x.shape[-1]; M = x.numel() // d
     if dres is not None: _chk(dres, 'dres', torch.float32)
     dx = torch.empty(x.shape, dtype=dx_dtype, device=x.device)
     nws = int(_lib.load().sconf_norm_bwd_workspace(M, d))               # per-workgroup column sums (no atomics, fixed order)
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
+    twin = twin and dx_dtype == torch.float32
+    dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if twin else None
+    cs = torch.empty(d, dtype=torch.float32, device=x.device) if twin else None
     _lib.call('sconf_norm_bwd', NORM_MODE[mode], _p(dy), _dt(dy), _p(x), _dt(x), _p(weight), _p(mean), _p(rstd), _p(dres),
-              _p(dx), _dt(dx), _p(dweight), _p(dbias), _p(ws), nws, M, d, float(eps), _stream())
-    return dx
+              _p(dx), _dt(dx), _p(dweight), _p(dbias), _p(ws), nws, _p(dx16), _p(cs), M, d, float(eps), _stream())
+    return (dx, dx16, cs) if twin else dx
 
 
 # ------------------------------------------------------------------------------------------------

@@ -84,7 +84,7 @@ def norm_fwd(x, weight, bias, mode, eps, out_dtype):
     return y.to(out_dtype), mean.reshape(-1), rstd.reshape(-1)
 
 
-def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbias):
+def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbias, twin=False):
     xf = x.to(f32).detach().clone().requires_grad_(True)
     w = weight.detach().clone().requires_grad_(True)
     b = torch.zeros_like(weight).requires_grad_(True)
@@ -98,6 +98,9 @@ def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbia
     if dres is not None: dx = dx + dres
     dweight += w.grad
     if dbias is not None and mode == 'layer_norm': dbias += b.grad
+    if twin and dx_dtype == f32:
+        dx16 = dx.to(torch.bfloat16)
+        return dx.to(dx_dtype), dx16, dx16.to(f32).reshape(-1, dx.shape[-1]).sum(0)
     return dx.to(dx_dtype)
 
 

@@ -189,6 +189,12 @@ def test_norm_fwd_bwd(ops, mode, d):
         close(dx, dxr, name=f'norm_bwd dx {mode}', tol=5e-3)
         close(dw, dwr, name='norm_bwd dw', tol=5e-3)
         if db is not None: close(db, dbr, name='norm_bwd db', tol=5e-3)
+        # twin outputs: bf16 copy of dx and its column sums from the same pass
+        dw2, db2 = torch.zeros(d).cuda(), (torch.zeros(d).cuda() if b is not None else None)
+        dx2, dx16, cs = ops.norm_bwd(dev(dy), dev(x), dev(w), mean, rstd, mode, eps, dev(dres), F32, dw2, db2, twin=True)
+        assert torch.equal(dx2, dx) and torch.equal(dx16, dx.to(BF))
+        close(cs, dx.to(BF).float().sum(0).cpu(), name='norm_bwd twin colsum', tol=2e-3)
+        close(dw2, dwr, name='norm_bwd dw (twin call)', tol=5e-3)
 
 
 # ------------------------------------------------------------------------------------------------ elementwise
