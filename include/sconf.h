@@ -78,7 +78,10 @@ int sconf_rotary_qkv(int bwd, void* qkv, const float* cos_tab, const float* sin_
 /* mode 0 softmax (sconformer_xl.py:242), mode 1 log_softmax (decoder.py:25); C <= 8192 classes. */
 int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, int y_dtype, int64_t M, int64_t C, sconf_stream_t stream);
 int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype,
-                      int64_t M, int64_t C, sconf_stream_t stream);
+                      float* colsum_out, float* workspace, int64_t M, int64_t C, sconf_stream_t stream);
+/* colsum_out (optional, f32 [C], accumulated): column sums of dx = the bias gradient of the Linear that produced the logits, from
+ * the same pass; needs `workspace` of sconf_softmax_bwd_workspace(M, C) floats. */
+int64_t sconf_softmax_bwd_workspace(int64_t M, int64_t C);
 
 /* out[n] += alpha * sum_m x[m][n]  (bias gradients). */
 int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, sconf_stream_t stream);

@@ -167,32 +167,51 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(const TI* __restrict__
 
 // MODE 0: softmax bwd   dx = y * (dy - sum(dy*y))          (y = probabilities)
 // MODE 1: log_softmax bwd dx = dy - exp(y) * sum(dy)         (y = log-probabilities)
+// A workgroup walks rows_per_block consecutive rows.  slab (optional, [gridDim.x][C] f32): the workgroup's column sums of the
+// dx it wrote (as stored, i.e. after rounding to TO) - the bias gradient of the Linear that produced the logits, without a
+// second pass over dx.
 template <typename TY, typename TG, typename TO, int MODE>
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__ y, const TG* __restrict__ dy,
-                                                          TO* __restrict__ dx, int C) {
+                                                          TO* __restrict__ dx, float* __restrict__ slab, long M, int C, int rows_per_block) {
     __shared__ float sh[16];
-    const long row = blockIdx.x;
-    float yv[SM_IT][4], gv[SM_IT][4];
-    float s = 0.f;
+    float cs[SM_IT][4];
 #pragma unroll
-    for (int it = 0; it < SM_IT; ++it) {
-        const int c = it * 1024 + threadIdx.x * 4;
-        if (c < C) {
-            load4(y + row * C + c, yv[it]); load4(dy + row * C + c, gv[it]);
+    for (int it = 0; it < SM_IT; ++it)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s += (MODE == 0) ? gv[it][e] * yv[it][e] : gv[it][e];
+        for (int e = 0; e < 4; ++e) cs[it][e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (long row = r0; row < r1; ++row) {
+        float yv[SM_IT][4], gv[SM_IT][4];
+        float s = 0.f;
+#pragma unroll
+        for (int it = 0; it < SM_IT; ++it) {
+            const int c = it * 1024 + threadIdx.x * 4;
+            if (c < C) {
+                load4(y + row * C + c, yv[it]); load4(dy + row * C + c, gv[it]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s += (MODE == 0) ? gv[it][e] * yv[it][e] : gv[it][e];
+            }
+        }
+        s = block_sum(s, sh);
+#pragma unroll
+        for (int it = 0; it < SM_IT; ++it) {
+            const int c = it * 1024 + threadIdx.x * 4;
+            if (c < C) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    o[e] = (MODE == 0) ? yv[it][e] * (gv[it][e] - s) : gv[it][e] - __expf(yv[it][e]) * s;
+                    cs[it][e] += (float)(TO)o[e];
+                }
+                store4(dx + row * C + c, o);
+            }
         }
     }
-    s = block_sum(s, sh);
+    if (slab) {
 #pragma unroll
-    for (int it = 0; it < SM_IT; ++it) {
-        const int c = it * 1024 + threadIdx.x * 4;
-        if (c < C) {
-            float o[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                o[e] = (MODE == 0) ? yv[it][e] * (gv[it][e] - s) : gv[it][e] - __expf(yv[it][e]) * s;
-            store4(dx + row * C + c, o);
+        for (int it = 0; it < SM_IT; ++it) {
+            const int c = it * 1024 + threadIdx.x * 4;
+            if (c < C) store4(slab + (long)blockIdx.x * C + c, cs[it]);
         }
     }
 }
@@ -302,13 +321,22 @@ SCONF_API int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, i
     return 0;
 }
 
+constexpr int SOFTMAX_BWD_SLABS = 2048;             // workgroups (= column-sum slabs) of the fused softmax backward
+SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, hipStream_t stream);
+// floats of scratch sconf_softmax_bwd needs when it also produces the column sums of dx
+SCONF_API int64_t sconf_softmax_bwd_workspace(int64_t M, int64_t C) { return (int64_t)std::min<long>(M, SOFTMAX_BWD_SLABS) * C; }
+
+// colsum_out (optional, f32 [C], ACCUMULATED): column sums of dx, i.e. the bias gradient of the Linear that produced the logits.
 SCONF_API int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void* dy, int dy_dtype, void* dx, int dx_dtype,
-                                int64_t M, int64_t C, hipStream_t stream) {
+                                float* colsum_out, float* workspace, int64_t M, int64_t C, hipStream_t stream) {
     SCONF_REQUIRE(C % 4 == 0 && C <= SM_IT * 1024 && C > 0, "sconf_softmax_bwd: C=%ld must be a multiple of 4 and <= 8192", (long)C);
     SCONF_REQUIRE(dx_dtype == SCONF_BF16 || dx_dtype == SCONF_F32, "sconf_softmax_bwd: bad dx dtype");
     if (M == 0) return 0;
-    dim3 g((unsigned)M), b(256);
-#define L(TY, TG, TO, MD) hipLaunchKernelGGL((softmax_bwd_kernel<TY, TG, TO, MD>), g, b, 0, stream, (const TY*)y, (const TG*)dy, (TO*)dx, (int)C)
+    SCONF_REQUIRE(!colsum_out || workspace, "sconf_softmax_bwd: colsum_out needs the workspace (sconf_softmax_bwd_workspace floats)");
+    const int rpb = colsum_out ? (int)cdiv(M, SOFTMAX_BWD_SLABS) : 1;
+    dim3 g((unsigned)cdiv(M, rpb)), b(256);
+    float* slab = colsum_out ? workspace : nullptr;
+#define L(TY, TG, TO, MD) hipLaunchKernelGGL((softmax_bwd_kernel<TY, TG, TO, MD>), g, b, 0, stream, (const TY*)y, (const TG*)dy, (TO*)dx, slab, (long)M, (int)C, rpb)
 #define D3(MD) \
     if (y_dtype == SCONF_BF16 && dy_dtype == SCONF_BF16) { if (dx_dtype == SCONF_BF16) L(bf16, bf16, bf16, MD); else L(bf16, bf16, float, MD); } \
     else if (y_dtype == SCONF_BF16) { if (dx_dtype == SCONF_BF16) L(bf16, float, bf16, MD); else L(bf16, float, float, MD); } \
@@ -318,6 +346,7 @@ SCONF_API int sconf_softmax_bwd(int mode, const void* y, int y_dtype, const void
 #undef D3
 #undef L
     SCONF_LAUNCH_OK("sconf_softmax_bwd");
+    if (colsum_out) return sconf_colsum(slab, SCONF_F32, colsum_out, (int64_t)g.x, C, C, 1.f, stream);     // += over the slabs
     return 0;
 }
 

@@ -394,9 +394,10 @@ class SelfCondFn(Function):
         dp = ops.gemm(dy16, wrt, 'nt')                                                # (M, V+1)
         dwr = _wgrad(dy16, p, pwr)
         dbr = _bgrad(dy16, pbr, colsum=dycs)
-        dl = ops.softmax_bwd(p, dp, False, BF16)
+        gbf = _G(pbf)                                                                  # bias gradient = column sums of dl, same pass
+        dl = ops.softmax_bwd(p, dp, False, BF16, colsum_into=gbf.t)
         dwf = _wgrad(dl, hn, pwf)
-        dbf = _bgrad(dl, pbf)
+        dbf = gbf.out()
         dhn = ops.gemm(dl, wft, 'nt')
         if has_norm:
             dnw, dnb = _G(pnw), _G(pnb)
@@ -440,9 +441,14 @@ class HeadFn(Function):
         nw, nb, wft, bff, hn, out = ctx.saved_tensors[:6]
         sn = ctx.saved_tensors[6:]
         dout = dout.contiguous()
-        dl = ops.cast(dout, BF16) if return_logits else ops.softmax_bwd(out, dout, True, BF16)
+        if return_logits:
+            dl = ops.cast(dout, BF16)
+            dbf = _bgrad(dl, pbf)
+        else:
+            gbf = _G(pbf)
+            dl = ops.softmax_bwd(out, dout, True, BF16, colsum_into=gbf.t)
+            dbf = gbf.out()
         dwf = _wgrad(dl, hn, pwf)
-        dbf = _bgrad(dl, pbf)
         g = ops.gemm(dl, wft, 'nt')                                                    # (M,d) bf16
         dnw, dnb = _G(pnw if n_norms > 0 else None), _G(pnb if n_norms > 0 else None)
         for i in reversed(range(n_norms)):

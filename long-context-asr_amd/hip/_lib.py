@@ -25,7 +25,7 @@ PROTOTYPES = {
     'sconf_cast_shadows': [vp, i64, i64, vp],
     'sconf_rotary_qkv': [i32, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_softmax_fwd': [i32, vp, i32, vp, i32, i64, i64, vp],
-    'sconf_softmax_bwd': [i32, vp, i32, vp, i32, vp, i32, i64, i64, vp],
+    'sconf_softmax_bwd': [i32, vp, i32, vp, i32, vp, i32, vp, vp, i64, i64, vp],
     'sconf_colsum': [vp, i32, vp, i64, i64, i64, f32, vp],
     'sconf_mask_rows': [vp, i32, vp, i64, i64, i64, vp],
     'sconf_attn_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, i32, i32, f32, vp],
@@ -49,7 +49,7 @@ PROTOTYPES = {
     'sconf_sumsq': [vp, i64, vp, vp],
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp],
 }
-PLAIN = {'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
+PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 
 
 def load():

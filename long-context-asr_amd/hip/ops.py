@@ -227,11 +227,19 @@ def softmax_fwd(x: torch.Tensor, log: bool, out_dtype: torch.dtype) -> torch.Ten
     return y
 
 
-def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, log: bool, out_dtype: torch.dtype) -> torch.Tensor:
+def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, log: bool, out_dtype: torch.dtype,
+                colsum_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of softmax / log_softmax over the last dim.  colsum_into (f32, C elements): += column sums of the returned dx
+    (the bias gradient of the Linear that produced the logits), computed in the same pass."""
     _chk(y, 'y'); _chk(dy, 'dy')
     Cn = y.shape[-1]; M = y.numel() // Cn
     dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)
-    _lib.call('sconf_softmax_bwd', int(log), _p(y), _dt(y), _p(dy), _dt(dy), _p(dx), _dt(dx), M, Cn, _stream())
+    ws = None
+    if colsum_into is not None:
+        _chk(colsum_into, 'colsum_into', torch.float32)
+        if colsum_into.numel() != Cn: raise ValueError('colsum_into must have one element per class')
+        ws = torch.empty(int(_lib.load().sconf_softmax_bwd_workspace(M, Cn)), dtype=torch.float32, device=y.device)
+    _lib.call('sconf_softmax_bwd', int(log), _p(y), _dt(y), _p(dy), _dt(dy), _p(dx), _dt(dx), _p(colsum_into), _p(ws), M, Cn, _stream())
     return dx
 
 

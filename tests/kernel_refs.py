@@ -148,11 +148,13 @@ def softmax_fwd(x, log, out_dtype):
     return (F.log_softmax(xf, -1) if log else F.softmax(xf, -1)).to(out_dtype)
 
 
-def softmax_bwd(y, dy, log, out_dtype):
+def softmax_bwd(y, dy, log, out_dtype, colsum_into=None):
     yf, g = y.to(f32), dy.to(f32)
     if log: dx = g - yf.exp() * g.sum(-1, keepdim=True)
     else: dx = yf * (g - (g * yf).sum(-1, keepdim=True))
-    return dx.to(out_dtype)
+    dx = dx.to(out_dtype)
+    if colsum_into is not None: colsum_into += dx.to(f32).reshape(-1, dx.shape[-1]).sum(0).view(colsum_into.shape)
+    return dx
 
 
 def colsum_(x, out, alpha=1.0):

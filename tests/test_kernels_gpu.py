@@ -254,6 +254,16 @@ def test_softmax(ops, C):
         dy = rnd(M, C, dtype=yd, seed=5)
         dx = ops.softmax_bwd(dev(yr), dev(dy), log, BF)
         close(dx, R.softmax_bwd(yr, dy, log, BF), name=f'softmax_bwd log={log}')
+        cs = torch.ones(C).cuda()                                   # fused column sums (bias gradient), accumulated
+        dx2 = ops.softmax_bwd(dev(yr), dev(dy), log, BF, colsum_into=cs)
+        assert torch.equal(dx2, dx)
+        close(cs, 1.0 + dx.float().sum(0).cpu(), name='softmax_bwd colsum', tol=2e-3)
+    big = rnd(5000, C, dtype=F32, scale=2.0)                        # more rows than column-sum slabs: several rows per workgroup
+    yb = torch.softmax(big, -1).to(BF); db_ = rnd(5000, C, seed=9)
+    cs = torch.zeros(C).cuda()
+    dxb = ops.softmax_bwd(dev(yb), dev(db_), False, BF, colsum_into=cs)
+    close(dxb, R.softmax_bwd(yb, db_, False, BF), name='softmax_bwd many rows')
+    close(cs, dxb.float().sum(0).cpu(), name='softmax_bwd colsum many rows', tol=2e-3)
 
 
 def test_colsum_and_mask(ops):
