@@ -3,6 +3,12 @@
 #include "common.h"
 
 namespace {
+// raw 4-element vectors: loads issued early, converted when consumed
+template <typename T> struct Raw4;
+template <> struct Raw4<float> { float4 v; __device__ __forceinline__ void get(float (&o)[4]) const { o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; } };
+template <> struct Raw4<bf16>  { bf16x4 v; __device__ __forceinline__ void get(float (&o)[4]) const {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (float)v[e]; } };
 
 // ---------------------------------------------------------------------------------------------
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ s, bf16* __restrict__ d, long n) {
@@ -180,14 +186,33 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__
 #pragma unroll
         for (int e = 0; e < 4; ++e) cs[it][e] = 0.f;
     const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    // raw loads of the NEXT row are issued before the current row's block-wide reduction (a serial chain per row otherwise)
+    struct Raw { decltype(Raw4<TY>().v) y[SM_IT]; decltype(Raw4<TG>().v) g[SM_IT]; };
+    auto fetch = [&](long row) {
+        Raw r;
+#pragma unroll
+        for (int it = 0; it < SM_IT; ++it) {
+            const int c = it * 1024 + threadIdx.x * 4;
+            if (c < C) {
+                r.y[it] = *reinterpret_cast<const decltype(Raw4<TY>().v)*>(y + row * C + c);
+                r.g[it] = *reinterpret_cast<const decltype(Raw4<TG>().v)*>(dy + row * C + c);
+            }
+        }
+        return r;
+    };
+    Raw cur;
+    if (r0 < r1) cur = fetch(r0);
     for (long row = r0; row < r1; ++row) {
+        Raw nxt;
+        if (row + 1 < r1) nxt = fetch(row + 1);
         float yv[SM_IT][4], gv[SM_IT][4];
         float s = 0.f;
 #pragma unroll
         for (int it = 0; it < SM_IT; ++it) {
             const int c = it * 1024 + threadIdx.x * 4;
             if (c < C) {
-                load4(y + row * C + c, yv[it]); load4(dy + row * C + c, gv[it]);
+                Raw4<TY> ry; ry.v = cur.y[it]; ry.get(yv[it]);
+                Raw4<TG> rg; rg.v = cur.g[it]; rg.get(gv[it]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) s += (MODE == 0) ? gv[it][e] * yv[it][e] : gv[it][e];
             }
@@ -206,6 +231,7 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(const TY* __restrict__
                 store4(dx + row * C + c, o);
             }
         }
+        cur = nxt;
     }
     if (slab) {
 #pragma unroll

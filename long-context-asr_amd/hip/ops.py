@@ -120,8 +120,10 @@ def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
         # 256x256-tile kernel (gemm256.hip): one workgroup per CU, so aim at one full round of (tile, split) items; with
         # very few tiles the per-split slabs get too many and the 128x128 kernel below does better
         tiles256 = (M // 256) * (N // 256)
-        if 16 <= tiles256 <= n_cus and nkt >= 32:
-            return max(1, min(n_cus // tiles256, nkt // 8))
+        if tiles256 <= n_cus and nkt >= 32:
+            sk = max(1, min(n_cus // tiles256, nkt // 32))               # at least 32 K-tiles per work item
+            if tiles256 * sk * 4 >= 3 * n_cus:                           # the kernel's own eligibility rule: >= 3/4 of a round
+                return sk
     tiles = ((M + 127) // 128) * ((N + 127) // 128)
     slots = 2 * n_cus
     if tiles >= slots or nkt < 32:
