@@ -1,4 +1,5 @@
-"""Diagnostic: TN vs NT main-loop efficiency of the 256-row GEMM kernel at square long-K shapes (no split-K, plain epilogue)."""
+"""Diagnostic: TN (weight-gradient) main-loop rate of the 256-row GEMM kernel; with a probe build (make PROBE=1) SCONF_GEMM_DEBUG=2
+removes the epilogue."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,11 +14,17 @@ def t(fn, n=10):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / n)
     return best
-for m, n, k in [(4096, 4096, 4096), (8192, 8192, 8192), (3072, 768, 32768 // 7 // 64 * 64 * 7)]:
-    a = torch.randn(m, k, device='cuda').bfloat16(); b = torch.randn(n, k, device='cuda').bfloat16()
-    at = a.t().contiguous(); bt = b.t().contiguous()
-    for lay, A, B, kw in [('nt', a, b, {}), ('nt f32', a, b, dict(out_dtype=torch.float32)), ('tn f32', at, bt, dict(out_dtype=torch.float32)),
-                          ('tn f32 split7', at, bt, dict(out_dtype=torch.float32, split_k=7))]:
-        if 'split' in lay and m != 3072: continue
-        ms = t(lambda: ops.gemm(A, B, lay.split()[0], **kw))
-        print(f'{m}x{n}x{k} {lay:14s} {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:7.0f} TF', flush=True)
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 131072
+for m, n, sp in [(3072, 768, 7), (768, 3072, 7), (4096, 4096, 1), (4096, 768, 5)]:
+    k = K if sp > 1 else 4096
+    a = torch.randn(k, m, device='cuda').bfloat16(); b = torch.randn(k, n, device='cuda').bfloat16()
+    for dbg in ('0', '2'):
+        os.environ['SCONF_GEMM_DEBUG'] = dbg
+        ms = t(lambda: ops.gemm(a, b, 'tn', out_dtype=torch.float32, split_k=sp))
+        print(f'tn {m}x{n}x{k} split {sp} debug={dbg}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:6.0f} TF', flush=True)
+    if sp == 1:
+        at = a.t().contiguous(); bt = b.t().contiguous()
+        for dbg in ('0', '2'):
+            os.environ['SCONF_GEMM_DEBUG'] = dbg
+            ms = t(lambda: ops.gemm(at, bt, 'nt', out_dtype=torch.float32))
+            print(f'nt {m}x{n}x{k} debug={dbg}: {ms*1e3:8.1f} us {2.0*m*n*k/ms/1e9:6.0f} TF', flush=True)
