@@ -112,11 +112,11 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const bf16* __restric
 // (i, j) in registers (dbias += g at the centre tap, which visits every output exactly once).  Workgroup reduction over the
 // position lanes through LDS, then one atomic per sum.
 template <int CW>
-__global__ __launch_bounds__(256) void dwconv2d_bwd_kernel(const bf16* __restrict__ dout, const float* __restrict__ w,
+__global__ __launch_bounds__(512) void dwconv2d_bwd_kernel(const bf16* __restrict__ dout, const float* __restrict__ w,
                                                            const bf16* __restrict__ pre_in, bf16* __restrict__ dpre_in,
                                                            float* __restrict__ dw, float* __restrict__ dbias,
                                                            int Ti, int Fi, int C, int To, int Fo, int PL, int iters) {
-    __shared__ float red[256];
+    __shared__ float red[512];
     const int cgs = C / CW;
     struct { int cg, plane, c0; bool active; } g;
     g.cg = threadIdx.x % cgs; g.plane = threadIdx.x / cgs; g.c0 = g.cg * CW; g.active = g.plane < PL;
@@ -562,11 +562,13 @@ SCONF_API int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void*
     SUB_REQ("sconf_sub_dwconv_bwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
     if (B * Ti * Fi == 0) return 0;
-    long target = 1024; int cw = 4;                            // few workgroups: each ends with 10 x CW x C/CW atomics
+    long target = 512; int cw = 4;                             // few, fat (512-thread) workgroups: each ends with 10 x C atomics
     if (const char* e = getenv("SCONF_SUB_DWBWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { cw = a; target = t; } }   // tuning
     const int cgs = (int)(C / cw);
     SCONF_REQUIRE(cgs <= 256, "sconf_sub_dwconv_bwd: C too large");
-    const int PL = std::max(1, 256 / cgs), threads = (cgs * PL + 63) / 64 * 64;
+    int nthr = 512;
+    if (const char* e = getenv("SCONF_SUB_DWBWD_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) nthr = v; }     // tuning
+    const int PL = std::max(1, nthr / cgs), threads = (cgs * PL + 63) / 64 * 64;
     const long npos = (long)Ti * Fi, per_b = std::max<long>(1, target / B);
     const int iters = (int)std::max<long>(1, cdiv(npos, (long)PL * per_b));
     dim3 grid(cdiv(npos, (long)PL * iters), (unsigned)B);

@@ -28,6 +28,8 @@ pre1 = torch.randn(B, Ti, Fi, C, device='cuda').bfloat16()
 dd2 = torch.randn(B, Ti // 2, Fi // 2, C, device='cuda').bfloat16()
 gw, gbv = torch.zeros(C, 9, device='cuda'), torch.zeros(C, device='cuda')
 print(f'dwconv fwd: {t(lambda: ops.sub_dwconv_fwd(pre1, wd, bd)):.3f} ms')
-for cfg in ('8,512', '4,256', '4,512', '4,1024', '4,2048', '4,4096'):
-    os.environ['SCONF_SUB_DWBWD_CFG'] = cfg
-    print(f'dwconv bwd cfg {cfg}: {t(lambda: ops.sub_dwconv_bwd(dd2, wd, pre1, gw, gbv)):.3f} ms')
+for thr in ('256', '512'):
+    os.environ['SCONF_SUB_DWBWD_THREADS'] = thr
+    for cfg in ('4,512', '4,1024', '4,2048', '8,512', '8,1024'):
+        os.environ['SCONF_SUB_DWBWD_CFG'] = cfg
+        print(f'dwconv bwd threads {thr} cfg {cfg}: {t(lambda: ops.sub_dwconv_bwd(dd2, wd, pre1, gw, gbv)):.3f} ms')
