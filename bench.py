@@ -88,7 +88,9 @@ class GemmTimer:
             e0.record()
             out = inner(a, b, layout, **kw)
             e1.record()
-            timer.log.append((var, 2.0 * m * n * k))
+            nbytes = 2.0 * (m * k + n * k) + m * n * (4 if kw.get('out_dtype') == torch.float32 or kw.get('accum') is not None else 2)
+            nbytes += m * n * (2 * bool(kw.get('save_pre')) + 4 * (kw.get('resid') is not None) + 2 * (kw.get('aux') is not None))
+            timer.log.append((var, 2.0 * m * n * k, nbytes))
             return out
         ops.gemm = gemm
 
@@ -105,16 +107,27 @@ class GemmTimer:
         if not self.used:
             return None
         per = {}
-        for i, (var, fl) in enumerate(self.log):
+        for i, (var, fl, nb) in enumerate(self.log):
             ms = self.pool[2 * i].elapsed_time(self.pool[2 * i + 1])
-            d = per.setdefault(var, [0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl
+            d = per.setdefault(var, [0, 0.0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl; d[3] += nb
         top = max(per, key=lambda v: per[v][1])
-        n, ms, fl = per[top]
+        n, ms, fl, nb = per[top]
         ach = fl / (ms * 1e-3)
         tot = sum(self.warm_flops.values()) or 1.0
         others = {GEMM_KERNELS.get(v, str(v)): round(f / tot, 3) for v, f in sorted(self.warm_flops.items())}
+        # HBM bytes per launch of this kernel from the PMC passes kept under profiles/ (FETCH_SIZE / WRITE_SIZE with the gfx950
+        # correction, see the file's header); the operand / output bytes of the same launches are computed here
+        traffic, src = None, None
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_v6.json')))
+            key = GEMM_KERNELS.get(top, '').split(' (')[0]
+            if key in tj['kernels']:
+                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r01_hbm_traffic_v6.json (PMC, B=64 run)'
+        except Exception:
+            pass
         return dict(bound='mfma', kernel=GEMM_KERNELS.get(top, str(top)), achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
-                    unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=None, launches=n,
+                    unit='TFLOP/s', frac=round(ach / PEAK_BF16_DENSE, 4), traffic=traffic, traffic_unit='bytes per launch',
+                    traffic_source=src, algorithmic_bytes_per_launch=int(nb / n), launches=n,
                     avg_launch_us=round(ms * 1e3 / n, 2), gemm_flop_share_by_kernel=others)
 
 
