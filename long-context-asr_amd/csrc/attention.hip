@@ -34,7 +34,28 @@ struct AttnParams {
     int B, N, H;
     int win_left, win_right;          // -1 = unbounded
     float scale;                      // 1/sqrt(D)
+    int xcd_remap;                    // 1: XCD-contiguous workgroup order (decode_block)
 };
+
+// Workgroup -> (batch, head, row block) for a 1-D launch of nx * H * B workgroups.  The hardware deals consecutive workgroup ids
+// to the 8 XCDs round-robin, so with the natural order the 8 row blocks of one (b, h) land on 8 different XCDs and every XCD's
+// 4 MiB L2 sees the K/V (or Q/dO) tiles of ALL ~32 concurrently running (b, h) pairs: measured 3.6-4.2 GB of fabric reads per
+// launch against 0.4 GB of operands (9x, once per XCD).  The remap gives each XCD a CONTIGUOUS range of logical ids (bijective
+// for any total) and orders logical ids row-block-fastest, so the ~32 workgroups resident on an XCD cover a few whole (b, h).
+struct BlkId { int b, h, x; };
+__device__ __forceinline__ BlkId decode_block(const AttnParams& p, int nx) {
+    const int total = nx * p.H * p.B, v = blockIdx.x;
+    int lid = v;
+    if (p.xcd_remap) {
+        const int q = total >> 3, r = total & 7, xcd = v & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+    }
+    BlkId o;
+    o.x = lid % nx;
+    const int bh = lid / nx;
+    o.h = bh % p.H; o.b = bh / p.H;
+    return o;
+}
 
 template <int D> __device__ __forceinline__ int tile_off(int row, int ch) {
     const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
@@ -178,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;                     // bytes of one 64-row tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 127) / 128);
+    const int b = bid.b, h = bid.h, qb0 = bid.x * 128, q0 = qb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -283,7 +305,8 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = KT * 2 * D;                     // bytes of one stage tile
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 256, q0 = qb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 255) / 256);
+    const int b = bid.b, h = bid.h, qb0 = bid.x * 256, q0 = qb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -418,7 +441,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
     constexpr int TB = 32 * 2 * D;                     // Q tile / dO tile bytes (32 rows)
     constexpr int SB = 2 * TB + 256;                   // one stage: Q | dO | lse2[32] | delta[32]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 128, k0 = kb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 127) / 128);
+    const int b = bid.b, h = bid.h, kb0 = bid.x * 128, k0 = kb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -546,7 +570,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
     constexpr int TB = QR * 2 * D;                     // Q tile / dO tile bytes
     constexpr int SB = 2 * TB + 512;                   // one stage: Q | dO | lse2[64] | delta[64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, kb0 = blockIdx.x * 256, k0 = kb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 255) / 256);
+    const int b = bid.b, h = bid.h, kb0 = bid.x * 256, k0 = kb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -655,7 +680,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = 64 * 2 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 128, q0 = qb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 127) / 128);
+    const int b = bid.b, h = bid.h, qb0 = bid.x * 128, q0 = qb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -735,7 +761,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int TB = KT * 2 * D;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, qb0 = blockIdx.x * 256, q0 = qb0 + wave * 32;
+    const BlkId bid = decode_block(p, (p.N + 255) / 256);
+    const int b = bid.b, h = bid.h, qb0 = bid.x * 256, q0 = qb0 + wave * 32;
     const int len = p.lengths ? p.lengths[b] : p.N;
     const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
@@ -844,14 +871,15 @@ SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* 
     p.v_sb = v_strides[0]; p.v_sn = v_strides[1]; p.v_sh = v_strides[2];
     p.o_sb = o_strides[0]; p.o_sn = o_strides[1]; p.o_sh = o_strides[2];
     p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
-    dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
+    dim3 grid((unsigned)(cdiv(N, 128) * H * B)), block(256);
+    { const char* ex = getenv("SCONF_ATTN_XCD"); p.xcd_remap = !(ex && ex[0] == '0'); }       // A/B switch, read per call
     set_lds_attrs();
     const char* e8 = getenv("SCONF_ATTN_WIDE");            // "0" keeps the 4-wave kernels (A/B, tests); read per call
     const bool wide = !(e8 && e8[0] == '0') && N >= 256;
     if (D == 128 && wide) {
         static bool attr_set = false;
         if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
-        hipLaunchKernelGGL((attn_fwd8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), 4 * 128 * 256, stream, p);
+        hipLaunchKernelGGL((attn_fwd8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
     } else if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     else          hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
     SCONF_LAUNCH_OK("sconf_attn_fwd");
@@ -883,7 +911,8 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
     p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
     const long rows = B * N * H;
     set_lds_attrs();
-    dim3 grid(cdiv(N, 128), (unsigned)H, (unsigned)B), block(256);
+    dim3 grid((unsigned)(cdiv(N, 128) * H * B)), block(256);
+    { const char* ex = getenv("SCONF_ATTN_XCD"); p.xcd_remap = !(ex && ex[0] == '0'); }       // A/B switch, read per call
     if (D == 128) {
         hipLaunchKernelGGL((attn_delta_kernel<128>), dim3(cdiv(rows * 16, 256)), dim3(256), 0, stream, p);
         const char* e8 = getenv("SCONF_ATTN_DKDV8");           // "0" keeps the 4-wave dK/dV kernel (A/B, tests); read per call
@@ -892,14 +921,14 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
             static bool attr_set = false;
             const int sh8 = 2 * (2 * 64 * 256 + 512) + 256 * 256;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, sh8); attr_set = true; }
-            hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), sh8, stream, p);
+            hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), sh8, stream, p);
         } else
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
         const char* eq = getenv("SCONF_ATTN_WIDE");
         if (!(eq && eq[0] == '0') && N >= 256) {
             static bool attr_set = false;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
-            hipLaunchKernelGGL((attn_bwd_dq8_kernel<128>), dim3(cdiv(N, 256), (unsigned)H, (unsigned)B), dim3(512), 4 * 128 * 256, stream, p);
+            hipLaunchKernelGGL((attn_bwd_dq8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
         } else
             hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     } else {
