@@ -326,6 +326,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
 #ifdef SCONF_GEMM_PROBE
     { const char* d = getenv("SCONF_GEMM_DEBUG"); p.debug = d ? atoi(d) : 0; }
 #endif
+    { const char* e = getenv("SCONF_GEMM_GM"); p.gm = e ? atoi(e) : 0; }                  // tuning: L2 patch height of the 256-row kernels
     const int nkt = cdiv(K, BK);
     p.k_per_split = cdiv(nkt, split_k) * BK;
     const int splits = cdiv(K, p.k_per_split);

@@ -39,7 +39,8 @@ using namespace gemm_tile;
 constexpr int TM = 256, TK = 64;
 constexpr int HT = 128 * 64 * 2;                   // one half-tile image, 16 KiB (B1 of the 192-wide tile uses half of it)
 constexpr int BUF = 4 * HT;                        // A0 | A1 | B0 | B1
-constexpr int GM2 = 4;                             // row panels per L2 patch (4 x 8 tiles = the 32 workgroups of one XCD)
+constexpr int GM2 = 4;                             // row panels per L2 patch (4 x 8 tiles = the 32 workgroups of one XCD);
+                                                   // 8 x 4 when the output is >= 8 tiles wide (measured +2-4 % at N >= 2304)
 
 typedef const __attribute__((address_space(1))) void* gptr;
 typedef __attribute__((address_space(3))) void* lptr;
@@ -124,14 +125,14 @@ template <bool KS, bool NARROW> __device__ __forceinline__ bf16x8 frag_b(const c
 
 // Work items (K-split, 256x256 tile): XCD-contiguous ids, split-major, GM2 x tiles_n patches (see gemm.hip tile_coords).
 struct Item { int m0, n0, kbeg, nkt, split; };
-struct Sched { int total, ntiles, tiles_m, tiles_n, tn; };
+struct Sched { int total, ntiles, tiles_m, tiles_n, tn, gm; };
 __device__ __forceinline__ Item item_coords(const GemmParams& p, const Sched& sc, int v) {
     const int qx = sc.total >> 3, rx = sc.total & 7, xcd = v & 7;
     const int lid = (xcd < rx ? xcd * (qx + 1) : rx * (qx + 1) + (xcd - rx) * qx) + (v >> 3);
     const int split = lid / sc.ntiles, t = lid - split * sc.ntiles;
-    const int per_group = GM2 * sc.tiles_n;
+    const int per_group = sc.gm * sc.tiles_n;
     const int g = t / per_group, r = t - g * per_group;
-    const int first_m = g * GM2, gm = min(GM2, sc.tiles_m - first_m);
+    const int first_m = g * sc.gm, gm = min(sc.gm, sc.tiles_m - first_m);
     Item w;
     w.m0 = (first_m + r % gm) * TM; w.n0 = (r / gm) * sc.tn;
     w.split = split;
@@ -247,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     Sched sc;
-    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits;
+    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits; sc.gm = p.gm > 0 ? p.gm : (sc.tiles_n >= 8 ? 2 * GM2 : GM2);
     if ((int)blockIdx.x >= sc.total) return;
 
     DmaOffs<KS, false, JH> oa; DmaOffs<KS, true, JH> ob;
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     Sched sc;
-    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits;
+    sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits; sc.gm = p.gm > 0 ? p.gm : (sc.tiles_n >= 8 ? 2 * GM2 : GM2);
     if ((int)blockIdx.x >= sc.total) return;
 
     DmaOffs<false, false, JH> oa; DmaOffs<false, true, JH> ob;

@@ -19,6 +19,7 @@ struct GemmParams {
     long split_stride;                              // split-K: partial-sum slab s lives at C + s * split_stride (f32)
     int k_per_split;                                // multiple of BK
     int splits;
+    int gm;                                         // row panels per L2 patch of the 256-row kernels (0 = default)
 #ifdef SCONF_GEMM_PROBE
     int debug;                                      // probe builds only (make PROBE=1; SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
 #endif
