@@ -111,8 +111,8 @@ int sconf_brn_finalize(const double* stats, int64_t count, float* running_mean, 
 int sconf_affine_silu_fwd(const void* h, const float* coef, void* y, int64_t M, int64_t d, sconf_stream_t stream);
 int sconf_convmod_bwd(const void* dy, const void* h, const void* g, const int32_t* lengths, const float* w,
                       const float* brn_weight, const float* coef, double* red, float* bcoef, void* dg, float* dw,
-                      float* dbias, float* dbrn_weight, float* dbrn_bias, int64_t B, int64_t N, int64_t d, int64_t ksize,
-                      int training, float eps, sconf_stream_t stream);
+                      float* dbias, float* dbrn_weight, float* dbrn_bias, float* dg_colsum, int64_t B, int64_t N, int64_t d,
+                      int64_t ksize, int training, float eps, sconf_stream_t stream);
 
 /* ConvSubsampling 'dw_striding' x8, channels-last (subsampling.py:276-321, 384-428). */
 int sconf_sub_conv0_fwd(const void* x, int x_dtype, const float* w, const float* bias, void* y, int64_t B, int64_t F,

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
                                                              const float* __restrict__ w, const float* __restrict__ coef,
                                                              const float* __restrict__ bcoef, bf16* __restrict__ dg,
                                                              float* __restrict__ dwt, float* __restrict__ dbias,
-                                                             int B, int N, int d, int TN) {
+                                                             float* __restrict__ dgcs, int B, int N, int d, int TN) {
     constexpr int P = (K - 1) / 2;
     __shared__ float redw[1024];
     const int CG = d / CV, spb = (N + TN - 1) / TN;
@@ -240,6 +240,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
     const int c0 = live ? geo.cg * CV : 0;
     const int L = len ? len[b] : N;
     float wk[K][CV], dhw[K][CV], aw[K][CV], gw[K][CV], gb[CV];
+    float sv[CV] = {0.f, 0.f, 0.f, 0.f}, sg2[CV] = {0.f, 0.f, 0.f, 0.f};   // column sums of dg (the pointwise_conv1 bias gradient)
     float mean[CV], is[CV], A[CV], Bc[CV], k0[CV], k1[CV], k2[CV];
     load4(coef + c0, mean); load4(coef + d + c0, is); load4(coef + 4 * d + c0, A); load4(coef + 5 * d + c0, Bc);
     load4(bcoef + c0, k0); load4(bcoef + d + c0, k1); load4(bcoef + 2 * d + c0, k2);
@@ -308,6 +309,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
                     const float sg = sigmoidf_((float)cur.cga[e]);
                     dv[e] = acc * sg; dgt[e] = acc * (float)cur.cva[e] * sg * (1.f - sg);
                 } else { dv[e] = 0.f; dgt[e] = 0.f; }
+                sv[e] += dv[e]; sg2[e] += dgt[e];
             }
             bf16* o = dg + ((long)b * N + n) * 2 * d;
             store4(o + c0, dv); store4(o + d + c0, dgt);
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(256) void dwconv_glu_bwd_kernel(const bf16* __restr
     slab_reduce_add<float>(gb, geo, redw, dbias, d);
 #pragma unroll
     for (int j = 0; j < K; ++j) slab_reduce_add<float>(gw[j], geo, redw, dwt + (long)j * d, d);
+    if (dgcs) { slab_reduce_add<float>(sv, geo, redw, dgcs, d); slab_reduce_add<float>(sg2, geo, redw, dgcs + d, d); }
 }
 
 int pick_tn(long B, long N, long CG) {
@@ -371,10 +374,10 @@ SCONF_API int sconf_affine_silu_fwd(const void* h, const float* coef, void* y, i
 // Backward of [GLU -> mask -> dwconv -> BatchRenorm -> SiLU].  dy: grad wrt the SiLU output (B,N,d) bf16.
 // red: f64 [2][d] scratch PRE-ZEROED; bcoef: f32 [3][d] scratch.  Writes dg (B,N,2d) bf16; ACCUMULATES (+=)
 // d(dw weight) TRANSPOSED as [k][d] (the caller transposes the tiny tensor back), d(dw bias) [d], d(brn weight) [d],
-// d(brn bias) [d].
+// d(brn bias) [d]; dg_colsum (optional, [2d]) += column sums of dg = the pointwise_conv1 bias gradient (convolution.py:100).
 SCONF_API int sconf_convmod_bwd(const void* dy, const void* h, const void* g, const int32_t* lengths, const float* w,
                                 const float* brn_weight, const float* coef, double* red, float* bcoef, void* dg,
-                                float* dw, float* dbias, float* dbrn_weight, float* dbrn_bias,
+                                float* dw, float* dbias, float* dbrn_weight, float* dbrn_bias, float* dg_colsum,
                                 int64_t B, int64_t N, int64_t d, int64_t ksize, int training, float eps, hipStream_t stream) {
     SCONF_REQUIRE(d % CV == 0, "sconf_convmod_bwd: d must be a multiple of 4");
     const long M = B * N;
@@ -389,7 +392,7 @@ SCONF_API int sconf_convmod_bwd(const void* dy, const void* h, const void* g, co
                        bcoef, dbrn_weight, dbrn_bias, (int)d, training, eps);
     const int TN = pick_tn(B, N, CG);
     dim3 grid(cdiv(B * cdiv(N, TN), spbk), cdiv(CG, cpb)), block(256);
-#define L(KK) hipLaunchKernelGGL((dwconv_glu_bwd_kernel<KK>), grid, block, 0, stream, (const bf16*)dy, (const bf16*)h, (const bf16*)g, lengths, w, coef, bcoef, (bf16*)dg, dw, dbias, (int)B, (int)N, (int)d, TN)
+#define L(KK) hipLaunchKernelGGL((dwconv_glu_bwd_kernel<KK>), grid, block, 0, stream, (const bf16*)dy, (const bf16*)h, (const bf16*)g, lengths, w, coef, bcoef, (bf16*)dg, dw, dbias, dg_colsum, (int)B, (int)N, (int)d, TN)
     switch (ksize) { case 3: L(3); break; case 5: L(5); break; case 7: L(7); break; case 9: L(9); break;
         default: return sconf_set_error("sconf_convmod_bwd: unsupported kernel size %ld (3,5,7,9)", (long)ksize); }
 #undef L

@@ -207,7 +207,11 @@ class NormFn(Function):
     def backward(ctx, dy):
         x, weight, mean, rstd = ctx.saved_tensors
         dw, db = _G(ctx.P[0]), _G(ctx.P[1])
-        dx = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, x.dtype, dw.t, db.t)
+        if x.dtype == F32:                      # norm_out: the layer's last block (ff2) receives dx as its output gradient
+            dx, dx16, cs = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, F32, dw.t, db.t, twin=True)
+            _park_twin(dx, dx16, cs)
+        else:
+            dx = ops.norm_bwd(dy.contiguous(), x, weight, mean, rstd, ctx.mode, ctx.eps, None, x.dtype, dw.t, db.t)
         return dx, dw.out(), db.out(), None, None, None
 
 
@@ -349,9 +353,10 @@ class ConvBlockFn(Function):
         dw2 = _wgrad(dy16, y2, pw2)
         db2 = _bgrad(dy16, pb2, colsum=dycs)
         ddw, dbdw, dbrnw, dbrnb = _G(pwdw, wdw2.shape), _G(pbdw), _G(pbrnw), _G(pbrnb)
-        dg = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw.t, dbdw.t, dbrnw.t, dbrnb.t)
+        dg, dgcs = ops.convmod_bwd(dy2, hc, g, lengths, wdw2, brn_w, coef, B, N, training, BRN_EPS, ddw.t, dbdw.t, dbrnw.t, dbrnb.t,
+                                   colsum=pb1 is not None)
         dw1 = _wgrad(dg, h, pw1)
-        db1 = _bgrad(dg, pb1)
+        db1 = _bgrad(dg, pb1, colsum=dgcs)
         dh = ops.gemm(dg, w1t, 'nt')
         dnw, dnb = _G(pnw), _G(pnb)
         dx = _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dy if residual else None, dnw.t, dnb.t)

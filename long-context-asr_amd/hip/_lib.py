@@ -33,7 +33,7 @@ PROTOTYPES = {
     'sconf_glu_dwconv_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_brn_finalize': [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     'sconf_affine_silu_fwd': [vp, vp, vp, i64, i64, vp],
-    'sconf_convmod_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, vp],
+    'sconf_convmod_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, vp],
     'sconf_sub_conv0_fwd': [vp, i32, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_dwconv_fwd': [vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_dwconv_bwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],

@@ -329,18 +329,20 @@ def affine_silu_fwd(h: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
 
 
 def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B: int, N: int, training: bool, eps: float,
-                dw, dbias, dbrn_weight, dbrn_bias) -> torch.Tensor:
-    """Backward of [GLU -> mask -> dwconv -> BatchRenorm -> SiLU]; returns dg (B*N, 2d) bf16; accumulates the 4 grads."""
+                dw, dbias, dbrn_weight, dbrn_bias, colsum: bool = False):
+    """Backward of [GLU -> mask -> dwconv -> BatchRenorm -> SiLU]; returns dg (B*N, 2d) bf16; accumulates the 4 grads.
+    colsum=True also returns the column sums of dg (2d,) f32 from the same pass (the bias gradient of the producing 1x1 conv)."""
     _chk(dy, 'dy', torch.bfloat16); _chk(h, 'h', torch.bfloat16); _chk(g, 'g', torch.bfloat16)
     d = h.shape[-1]; ks = w.numel() // d
     dg = torch.empty(B * N, 2 * d, dtype=torch.bfloat16, device=dy.device)
     red = torch.zeros(2, d, dtype=torch.float64, device=dy.device)
     bcoef = torch.empty(3, d, dtype=torch.float32, device=dy.device)
     dwt = torch.zeros(ks, d, dtype=torch.float32, device=dy.device)       # kernel accumulates the tap gradients as [k][d]
+    cs = torch.zeros(2 * d, dtype=torch.float32, device=dy.device) if colsum else None
     _lib.call('sconf_convmod_bwd', _p(dy), _p(h), _p(g), _p(lengths), _p(w), _p(brn_weight), _p(coef), _p(red), _p(bcoef), _p(dg),
-              _p(dwt), _p(dbias), _p(dbrn_weight), _p(dbrn_bias), B, N, d, ks, int(training), float(eps), _stream())
+              _p(dwt), _p(dbias), _p(dbrn_weight), _p(dbrn_bias), _p(cs), B, N, d, ks, int(training), float(eps), _stream())
     dw.add_(dwt.t())
-    return dg
+    return (dg, cs) if colsum else dg
 
 
 # ------------------------------------------------------------------------------------------------

@@ -270,7 +270,7 @@ def affine_silu_fwd(h, coef):
     return F.silu(h.to(f32) * coef[4] + coef[5]).to(torch.bfloat16)
 
 
-def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B, N, training, eps, dw, dbias, dbrn_weight, dbrn_bias):
+def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B, N, training, eps, dw, dbias, dbrn_weight, dbrn_bias, colsum=False):
     d = h.shape[-1]; ks = w.numel() // d
     hf = h.to(f32); gy = dy.to(f32)
     mean, s, r, dd, A, Bc = coef
@@ -300,7 +300,7 @@ def convmod_bwd(dy, h, g, lengths, w, brn_weight, coef, B, N, training, eps, dw,
         hh.backward(dh)
     dw += wf.grad.reshape(dw.shape)
     dbias += bf_.grad
-    return gf.grad.to(torch.bfloat16)
+    return (gf.grad.to(torch.bfloat16), gf.grad.sum(0)) if colsum else gf.grad.to(torch.bfloat16)
 
 
 def _half(n): return (n - 1) // 2 + 1
