@@ -189,6 +189,7 @@ def main():
     ap.add_argument('--config', default='c3', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--fwd-only', action='store_true', help='diagnostic (SURVEY 8d "also report fwd-only"): time the training-mode forward alone')
     ap.add_argument('--per-step', action='store_true', help='diagnostic: print per-step GPU times (HIP events, no extra syncs)')
     args = ap.parse_args()
 
@@ -227,6 +228,11 @@ def main():
 
     timer = GemmTimer()
     timer.install()
+    run_step = trainer.step
+    if args.fwd_only:
+        def run_step(audio, lengths, targets, tl):
+            with torch.no_grad():
+                return model(audio, length=lengths)['final_posteriors'][0, 0, 0]
 
     def sync():
         if world > 1:
@@ -236,7 +242,7 @@ def main():
     loss = None
     timer.count_only = True
     for i in range(max(args.warmup, 1)):
-        loss = trainer.step(audio, lengths, targets, tl)
+        loss = run_step(audio, lengths, targets, tl)
         if i == 0:
             timer.count_only = False
     timer.prepare(timer.calls * args.steps)
@@ -249,7 +255,7 @@ def main():
     for _ in range(args.steps):
         if args.per_step:
             e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
-        loss = trainer.step(audio, lengths, targets, tl)
+        loss = run_step(audio, lengths, targets, tl)
     if args.per_step:
         e = torch.cuda.Event(enable_timing=True); e.record(); step_ev.append(e)
     sync()
@@ -270,7 +276,7 @@ def main():
             'value': round(frames / dt, 1), 'unit': 'spectrogram-frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(dt / args.steps * 1e3, 2), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'bf16', 'data': 'synthetic',
-            'config': {'workload': cfg['name'] + ', fwd+CTC+bwd+clip+MADGRAD', 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
+            'config': {'workload': cfg['name'] + (', forward only (train mode, no_grad)' if args.fwd_only else ', fwd+CTC+bwd+clip+MADGRAD'), 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
                        'parallelism': f'dp{world}', 'loss_last_step': round(float(loss), 3)},
             'per_gpu_value': round(frames / dt / world, 1),
             'roofline': timer.summary(),
