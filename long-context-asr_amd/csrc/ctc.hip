@@ -147,6 +147,12 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
     __syncthreads();
     const float g = grad_out ? grad_out[b] : 1.f;          // per-sample upstream gradient
+    if (!(nl < INFINITY)) {
+        // No alignment fits (nll = +inf, zero_infinity=False): torch's backward evaluates exp(-inf + inf - lp) for every class
+        // of the sample's frames, i.e. the whole row is NaN - keep that signal instead of a half-valid gradient.
+        for (int c = threadIdx.x * 4; c < C; c += 1024) { float z[4] = {NAN, NAN, NAN, NAN}; store4(gr + c, z); }
+        return;
+    }
     for (int c = threadIdx.x * 4; c < C; c += 1024) {
         float v[4]; load4(lp + bt * C + c, v);
 #pragma unroll

@@ -300,7 +300,8 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
                               const void* aux, int64_t ldaux, void* pre, int64_t ldpre,
                               float alpha, int act, int out_f32, int split_k, hipStream_t stream) {
     SCONF_REQUIRE(layout >= 0 && layout <= 2, "sconf_gemm_bf16: bad layout %d", layout);
-    SCONF_REQUIRE(M > 0 && N > 0 && K > 0, "sconf_gemm_bf16: empty problem %ld x %ld x %ld", (long)M, (long)N, (long)K);
+    SCONF_REQUIRE(M >= 0 && N >= 0 && K > 0, "sconf_gemm_bf16: bad problem %ld x %ld x %ld (K must be positive)", (long)M, (long)N, (long)K);
+    if (M == 0 || N == 0) return 0;                    // an empty output (e.g. a batch with no rows): nothing to compute
     SCONF_REQUIRE(M < (1L << 31) && N < (1L << 31) && K < (1L << 31), "sconf_gemm_bf16: dims must be < 2^31");
     SCONF_REQUIRE(N % 4 == 0 && ldc % 4 == 0, "sconf_gemm_bf16: N and ldc must be multiples of 4 (N=%ld ldc=%ld)", (long)N, (long)ldc);
     if (layout == 0) SCONF_REQUIRE(N % 16 == 0 && ldc % 8 == 0, "sconf_gemm_bf16: the NT layout needs N %% 16 == 0 and ldc %% 8 == 0 (N=%ld ldc=%ld)", (long)N, (long)ldc);

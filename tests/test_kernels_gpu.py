@@ -432,6 +432,46 @@ def test_ctc(ops, B, N, C, S, ragged):
     if B > 1: assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
 
 
+def test_ctc_edge_cases(ops):
+    """torch.nn.CTCLoss(zero_infinity=False) semantics the reference relies on (exp/train.py:104): an EMPTY target is the
+    all-blank path; an alignment that cannot fit (repeats need a blank in between) gives nll = +inf, a NaN gradient inside
+    the sample's frames and an exact 0 behind input_length."""
+    B, N, C, S = 3, 20, 16, 6
+    g = torch.Generator().manual_seed(0)
+    lp = torch.log_softmax(torch.randn(B, N, C, generator=g), -1)
+    tg = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32)
+    tg[2] = 3                                                        # six equal labels need 11 frames
+    il = torch.tensor([20, 20, 8], dtype=torch.int32); tl = torch.tensor([6, 0, 6], dtype=torch.int32)
+    nll, ws = ops.ctc_fwd(dev(lp), dev(tg), dev(il), dev(tl), C - 1)
+    nllr, _ = R.ctc_fwd(lp, tg, il, tl, C - 1)
+    nll_c = nll.cpu()
+    assert torch.isinf(nllr[2]) and torch.isinf(nll_c[2]) and nll_c[2] > 0, (nll_c, nllr)
+    assert float(((nll_c[:2] - nllr[:2]) / nllr[:2]).abs().max()) < 1e-4, (nll_c, nllr)
+    assert abs(float(nll_c[1]) + float(lp[1, :, C - 1].sum())) < 1e-3            # empty target = minus the blank log-probs
+    go = torch.ones(B)
+    grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1).cpu()
+    gradr = R.ctc_bwd(lp, None, nllr, tg, il, tl, go, C - 1)
+    close(grad[:2], gradr[:2], name='ctc grad (feasible samples)', tol=2e-3)
+    assert torch.isnan(gradr[2, :8]).all() and torch.isnan(grad[2, :8]).all()   # same "infeasible" signal as torch
+    assert float(grad[2, 8:].abs().max()) == 0.0
+
+
+def test_empty_row_batches(ops):
+    """M = 0 (a recording whose last chunk is empty, a shrunk batch): every row-wise entry point returns without a launch."""
+    d = 64
+    x0 = torch.zeros(0, d, device='cuda'); w = torch.ones(d, device='cuda'); b = torch.zeros(d, device='cuda')
+    y, mean, rstd = ops.norm_fwd(x0, w, b, 'layer_norm', 1e-5, BF)
+    assert y.shape == (0, d) and mean.numel() == 0
+    assert ops.cast(x0, BF).shape == (0, d)
+    assert ops.softmax_fwd(x0, True, F32).shape == (0, d)
+    out = torch.zeros(d, device='cuda')
+    ops.colsum_(x0.to(BF), out)
+    assert float(out.abs().max()) == 0.0
+    c = ops.gemm(torch.zeros(0, 128, device='cuda', dtype=BF), torch.zeros(256, 128, device='cuda', dtype=BF), 'nt')
+    assert c.shape == (0, 256)
+    torch.cuda.synchronize()
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_madgrad_matches_reference_fixture(ops):
     fx = load_golden('madgrad')
