@@ -75,3 +75,89 @@ def load_checkpoint(args, model, optimizer=None, scheduler=None, sequence_schedu
         else:
             warnings.warn(f'Could not find {key} in checkpoint, skipping')
     return checkpoint.get('seen_ids', []), checkpoint.get('podcast_step', 0), checkpoint.get('epoch', 0)
+
+
+# ---- construction seam (lcasr/utils/general.py:24-95): config -> model class -> model -> optimiser + LR schedule ---------------
+def _get(cfg, key, default=None):
+    """Configs are dicts here and OmegaConf nodes (attribute access) in the reference: read either."""
+    if isinstance(cfg, dict):
+        return cfg.get(key, default)
+    return getattr(cfg, key, default) if not hasattr(cfg, 'get') else cfg.get(key, default)
+
+
+def get_model_class(config: Dict = {}, args={}):
+    """general.py:24-53.  Only the SConformerXL family is built on the MI355X path; the reference's other model classes
+    (Mamba, EncDec*, SCConformerMeta) are out of scope and refused by name rather than silently replaced."""
+    known = ['SCConformerXL', 'Mamba', 'EncDecSconformer', 'EncDecSconformerV2', 'SCConformerMeta']
+    arg_cls = getattr(args, 'model_class', None) if not isinstance(args, dict) else args.get('model_class')
+    if arg_cls is not None:
+        name = arg_cls
+    elif _get(config, 'model_class') is not None:
+        name = _get(config, 'model_class')
+    else:
+        warnings.warn('No model_class specified in model config or args, defaulting to SCConformerXL')
+        name = 'SCConformerXL'
+    assert name in known, f'Unknown model class {name}, must be one of {known}'
+    if name != 'SCConformerXL':
+        raise NotImplementedError(f'model class {name} is not part of the MI355X hot path (only SCConformerXL is)')
+    from ..models.sconformer_xl import SCConformerXL
+    return SCConformerXL
+
+
+def load_model(config: Dict, vocab_size: int, model_class=None):
+    """general.py:57-59: model_class(**config.model, vocab_size=vocab_size)."""
+    if model_class is None:
+        from ..models.sconformer_xl import SCConformerXL as model_class
+    return model_class(**dict(_get(config, 'model')), vocab_size=vocab_size)
+
+
+def load_optimizer(config: Dict, model: torch.nn.Module):
+    """general.py:61-95: optimiser from config['optimizer'] (name, args, weight_decay_groups) + the cosine LR schedule from
+    config['scheduler']['warmup_steps'].  'madgrad' is the fused flat-buffer MADGRAD (the reference's default and the only one
+    its paper configs use); 'adam' maps to torch.optim.Adam, which accepts the HIP path's gradients as they are.
+    Call it AFTER model.cuda(): the fused optimiser flattens the parameters where they live."""
+    from ..optim import MADGRAD
+    from .scheduling import CosineLRScheduler
+    opt = _get(config, 'optimizer')
+    optim_type = _get(opt, 'name')
+    allowed = ['adam', 'madgrad', 'mirrormadgrad']
+    assert optim_type in allowed, f'Unknown optimizer {optim_type}, must be one of {allowed}'
+    optim_args = dict(_get(opt, 'args'))
+    groups_mode = _get(opt, 'weight_decay_groups', 'default')
+    if groups_mode == 'default':
+        param_groups = model.get_param_groups(optim_args) if hasattr(model, 'get_param_groups') else model.parameters()
+    elif groups_mode == 'none':
+        param_groups = model.parameters()
+    else:
+        raise NotImplementedError(f'Unknown weight_decay_groups {groups_mode}, must be one of [default, none]')
+    if optim_type == 'madgrad':
+        optimizer = MADGRAD(param_groups, **optim_args)
+    elif optim_type == 'adam':
+        optimizer = torch.optim.Adam(param_groups, **optim_args)
+    else:
+        raise NotImplementedError('MirrorMADGRAD is not used by any SConformerXL config and is not implemented')
+    scheduler = CosineLRScheduler(optimizer=optimizer, warmup_steps=_get(_get(config, 'scheduler'), 'warmup_steps'),
+                                  peak_value=optim_args['lr'], final_value=0.0)
+    return optimizer, scheduler
+
+
+def avg_all_models_in_dir(path: str, out_path: str, model_name: str = 'step_105360.pt', trust_pickle: bool = False):
+    """general.py:175-194: uniform average of the 'model' state_dicts of <path>/*/<model_name>; the other entries of the first
+    checkpoint (minus optimizer / scheduler) are carried over.  Files are read with weights_only=True unless trust_pickle."""
+    folders = [el for el in sorted(os.listdir(path)) if os.path.exists(os.path.join(path, el, model_name))]
+    total = len(folders)
+    if total == 0:
+        raise FileNotFoundError(f'no {model_name} under {path}/*/')
+    avg, carried = None, None
+    for folder in folders:
+        ckpt = torch.load(os.path.join(path, folder, model_name), map_location='cpu', weights_only=not trust_pickle)
+        sd = ckpt['model']
+        if avg is None:
+            avg = {k: sd[k] * (1 / total) for k in sd}
+            carried = {k: ckpt[k] for k in ckpt if k not in ('model', 'optimizer', 'scheduler')}
+        else:
+            for k in sd:
+                avg[k] += sd[k] * (1 / total)
+    carried['model'] = avg
+    torch.save(carried, out_path)
+    return out_path
