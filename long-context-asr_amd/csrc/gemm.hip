@@ -22,6 +22,11 @@
 #include <algorithm>
 
 SCONF_API int sconf_num_cus(void);
+#ifdef SCONF_GEMM_PROBE
+static long long* g_probe_stamps = nullptr;
+// probe builds only: device buffer of 256 x 64 x 4 int64 that the 256x256 kernel fills with per-item time stamps (or null)
+SCONF_API int sconf_gemm_probe_stamps(void* buf) { g_probe_stamps = (long long*)buf; return 0; }
+#endif
 
 namespace {
 using namespace gemm_tile;
@@ -326,6 +331,8 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.pre = (bf16*)pre; p.ldpre = ldpre; p.alpha = alpha; p.act = act; p.out_f32 = out_f32;
 #ifdef SCONF_GEMM_PROBE
     { const char* d = getenv("SCONF_GEMM_DEBUG"); p.debug = d ? atoi(d) : 0; }
+    { const char* e = getenv("SCONF_GEMM_STAGGER"); p.stagger = e ? atoi(e) : 0; const char* f = getenv("SCONF_GEMM_STAGGER_MODE"); p.stagger_mode = f ? atoi(f) : 0; }
+    p.stamps = g_probe_stamps;
 #endif
     { const char* e = getenv("SCONF_GEMM_GM"); p.gm = e ? atoi(e) : 0; }                  // tuning: L2 patch height of the 256-row kernels
     const int nkt = cdiv(K, BK);

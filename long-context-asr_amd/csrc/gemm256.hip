@@ -157,7 +157,7 @@ struct Cursor {
 template <int W> struct RawBf;
 template <> struct RawBf<8> { typedef bf16x8 type; };
 template <> struct RawBf<4> { typedef bf16x4 type; };
-template <int ACT, bool RES, bool KS, int JH>
+template <int ACT, bool RES, bool KS, int JH, int FL = -1>
 __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[2][4][2 + JH], const Item& it, int wr, int wc, int lane) {
     constexpr int WC = 32 + 16 * JH, WH = 4 * JH;
     constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX;
@@ -169,7 +169,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
         for (int e = 0; e < 8; ++e) blo[e] = 0.f;
 #pragma unroll
         for (int e = 0; e < WH; ++e) bhi[e] = 0.f;
-        if (p.bias) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
+        if (FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
+        const long crow0 = (long)mbase * p.ldc, prow0 = (long)mbase * p.ldpre;      // per-lane row offsets; the rest is wave-uniform
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             typename RawBf<8>::type axlo[4];
@@ -198,14 +199,15 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
                 }
 #pragma unroll
                 for (int ii = 0; ii < 2; ++ii) {
-                    const int i = i2 + ii, m = mbase + 128 * h + 16 * i;
+                    const int i = i2 + ii;
                     float vlo[8], vhi[WH], alo[8], ahi[WH];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)axlo[i][e] : 0.f; }
 #pragma unroll
                     for (int e = 0; e < WH; ++e) { vhi[e] = acc[h][i][2 + (e >> 2)][e & 3]; ahi[e] = AUX ? (float)axhi[i][e] : 0.f; }
-                    epi_math_store<8, ACT>(p, vlo, blo, alo, rlo[ii], m, nlo, it.split);
-                    epi_math_store<WH, ACT>(p, vhi, bhi, ahi, rhi[ii], m, nhi, it.split);
+                    const long crow = crow0 + (long)(128 * h + 16 * i) * p.ldc, prow = prow0 + (long)(128 * h + 16 * i) * p.ldpre;
+                    epi_math_store_at<8, ACT, FL>(p, vlo, blo, alo, rlo[ii], crow + nlo, prow + nlo, it.split);
+                    epi_math_store_at<WH, ACT, FL>(p, vhi, bhi, ahi, rhi[ii], crow + nhi, prow + nhi, it.split);
                 }
             }
         }
@@ -232,6 +234,33 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
     }
 }
 
+// One specialised, contiguous epilogue per (activation, residual, bias, output type) combination the model's NT GEMMs use;
+// `kind` is computed once per launch (wave-uniform), everything else takes the runtime-flag path.
+//   0 bf16 plain   1 bf16 + bias   2 f32 + residual   3 f32 + residual + bias   4 gelu' save (no bias)   5 * aux   6 generic
+__device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
+    const bool b = p.bias != nullptr;
+    if (p.act == SCONF_ACT_GELU_DSAVE) return (!b && !p.out_f32 && !p.resid) ? 4 : 6;
+    if (p.act == SCONF_ACT_MULAUX) return (!b && !p.out_f32 && !p.resid && !p.pre) ? 5 : 6;
+    if (p.act != SCONF_ACT_NONE || p.pre) return 6;
+    if (!p.out_f32 && !p.resid) return b ? 1 : 0;
+    if (p.out_f32 && p.resid) return b ? 3 : 2;
+    return 6;
+}
+#define EPILOGUE_NT(JH_)                                                                                              \
+    switch (ekind) {                                                                                                  \
+        case 0: epilogue256<SCONF_ACT_NONE, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;                  \
+        case 1: epilogue256<SCONF_ACT_NONE, false, false, JH_, 1>(p, acc, cit, wr, wc, lane); break;                  \
+        case 2: epilogue256<SCONF_ACT_NONE, true, false, JH_, 2>(p, acc, cit, wr, wc, lane); break;                   \
+        case 3: epilogue256<SCONF_ACT_NONE, true, false, JH_, 3>(p, acc, cit, wr, wc, lane); break;                   \
+        case 4: epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;            \
+        case 5: epilogue256<SCONF_ACT_MULAUX, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;                \
+        default:                                                                                                      \
+            if (p.act == SCONF_ACT_GELU_DSAVE)  epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_>(p, acc, cit, wr, wc, lane); \
+            else if (p.act == SCONF_ACT_MULAUX) epilogue256<SCONF_ACT_MULAUX, false, false, JH_>(p, acc, cit, wr, wc, lane);     \
+            else if (p.resid)                   epilogue256<SCONF_ACT_NONE, true, false, JH_>(p, acc, cit, wr, wc, lane);        \
+            else                                epilogue256<SCONF_ACT_NONE, false, false, JH_>(p, acc, cit, wr, wc, lane);       \
+    }
+
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // leave the 4 youngest half-tiles in flight: 2 + 2 + 2 + JH DMA instructions per wave
 template <int JH> __device__ __forceinline__ void wait_window(bool streaming) {
@@ -250,7 +279,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     Sched sc;
     sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits; sc.gm = p.gm > 0 ? p.gm : (sc.tiles_n >= 8 ? 2 * GM2 : GM2);
     if ((int)blockIdx.x >= sc.total) return;
+#ifdef SCONF_GEMM_PROBE
+    if (p.stagger > 0) {
+        const int b = blockIdx.x;
+        const int ph = p.stagger_mode == 0 ? (b & 7) : p.stagger_mode == 1 ? ((b >> 3) & 7) : ((b + (b >> 3)) & 7);
+        for (int i = 0; i < ph * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+    int probe_item = 0;
+#endif
 
+    const int ekind = __builtin_amdgcn_readfirstlane(epilogue_kind(p));
     DmaOffs<KS, false, JH> oa; DmaOffs<KS, true, JH> ob;
     oa.set(p.lda, tid); ob.set(p.ldb, tid);
     auto issue_a = [&](const Cursor& c, int h) {
@@ -370,14 +408,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         }
         // ---- epilogue: both wave rows concurrently; one specialised, contiguous code path per (activation, residual) ------
 #ifdef SCONF_GEMM_PROBE
+        long long* st = (p.stamps && tid == 0 && probe_item < 64) ? p.stamps + ((long)blockIdx.x * 64 + probe_item) * 4 : nullptr;
+        if (st) { st[0] = __builtin_amdgcn_s_memrealtime(); st[1] = __builtin_amdgcn_s_memtime(); }
         if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
 #endif
         {
             if constexpr (KS) epilogue256<SCONF_ACT_NONE, false, true, JH>(p, acc, cit, wr, wc, lane);
-            else if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
-            else if (p.act == SCONF_ACT_MULAUX)     epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
-            else if (p.resid)                       epilogue256<SCONF_ACT_NONE, true, false, JH>(p, acc, cit, wr, wc, lane);
-            else                                    epilogue256<SCONF_ACT_NONE, false, false, JH>(p, acc, cit, wr, wc, lane);
+            else EPILOGUE_NT(JH);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -385,6 +422,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 2 + JH; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef SCONF_GEMM_PROBE
+        if (st) { st[2] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = __builtin_amdgcn_s_memtime(); }
+        ++probe_item;
+#endif
         __builtin_amdgcn_s_barrier();                 // re-align the two wave rows
         cv += gridDim.x;
         if (cv >= sc.total) break;
@@ -414,6 +455,7 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
     sc.tn = TN; sc.tiles_n = p.N / TN; sc.tiles_m = p.M / TM; sc.ntiles = sc.tiles_m * sc.tiles_n; sc.total = sc.ntiles * p.splits; sc.gm = p.gm > 0 ? p.gm : (sc.tiles_n >= 8 ? 2 * GM2 : GM2);
     if ((int)blockIdx.x >= sc.total) return;
 
+    const int ekind = __builtin_amdgcn_readfirstlane(epilogue_kind(p));
     DmaOffs<false, false, JH> oa; DmaOffs<false, true, JH> ob;
     oa.set(p.lda, tid); ob.set(p.ldb, tid);
     auto issue_a = [&](const Cursor& c, int h) {
@@ -515,10 +557,7 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
         if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
 #endif
         {
-            if (p.act == SCONF_ACT_GELU_DSAVE) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH>(p, acc, cit, wr, wc, lane);
-            else if (p.act == SCONF_ACT_MULAUX) epilogue256<SCONF_ACT_MULAUX, false, false, JH>(p, acc, cit, wr, wc, lane);
-            else if (p.resid)                   epilogue256<SCONF_ACT_NONE, true, false, JH>(p, acc, cit, wr, wc, lane);
-            else                                epilogue256<SCONF_ACT_NONE, false, false, JH>(p, acc, cit, wr, wc, lane);
+            EPILOGUE_NT(JH);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)

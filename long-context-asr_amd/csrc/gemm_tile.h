@@ -22,6 +22,8 @@ struct GemmParams {
     int gm;                                         // row panels per L2 patch of the 256-row kernels (0 = default)
 #ifdef SCONF_GEMM_PROBE
     int debug;                                      // probe builds only (make PROBE=1; SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
+    long long* stamps;                              // probe: per workgroup [64 items][4] {realtime at epilogue start, cycles at start, at end, after the next item's first wait}
+    int stagger, stagger_mode;                      // probe: start-up phase offsets between workgroups (units of 1024 cycles)
 #endif
 };
 
@@ -55,11 +57,18 @@ template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, E
 // work item, so that the instructions an item executes are contiguous); ACT = -1 reads p.act.  bs / ax / rs are the run's
 // bias, aux and residual values (zeros where absent), loaded by the caller - ahead of any store where it matters: on gfx950
 // loads and stores retire through one in-order counter, so a load issued behind a store waits for that store's completion.
-template <int W, int ACT = -1>
-__device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W], const float (&bs)[W], const float (&ax)[W],
-                                               const float (&rs)[W], int m, int n, int split) {
+// FL >= 0 also fixes, at compile time, whether a bias is added (bit 0) and whether the output is f32 (bit 1), and promises that
+// p.pre is only used by GELU_DSAVE: with those known the compiler emits no branch and - the point - no conservative
+// `s_waitcnt vmcnt(0)` in front of each bias use (which drained the stores of the previous row every time).  coff / poff are
+// the element offsets of the run in C and in pre (row offset computed once per row block by the caller).
+template <int W, int ACT = -1, int FL = -1>
+__device__ __forceinline__ void epi_math_store_at(const GemmParams& p, float (&v)[W], const float (&bs)[W], const float (&ax)[W],
+                                                  const float (&rs)[W], long coff, long poff, int split) {
     const int act = ACT >= 0 ? ACT : p.act;
-    if (p.bias) {
+    const bool has_bias = FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr;
+    const bool f32o = FL >= 0 ? (FL & 2) != 0 : p.out_f32 != 0;
+    const bool has_pre = FL >= 0 ? false : p.pre != nullptr;
+    if (has_bias) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] += bs[e];
     }
@@ -72,8 +81,8 @@ __device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W
         float dg[W];
 #pragma unroll
         for (int e = 0; e < W; ++e) gelu_both(v[e], v[e], dg[e]);
-        if (st) storev<W>(p.pre + (long)m * p.ldpre + n, dg);
-    } else if (p.pre) { if (st) storev<W>(p.pre + (long)m * p.ldpre + n, v); }
+        if (st) storev<W>(p.pre + poff, dg);
+    } else if (has_pre) { if (st) storev<W>(p.pre + poff, v); }
     if (act == SCONF_ACT_MULAUX) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] *= ax[e];
@@ -93,8 +102,13 @@ __device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W
 #pragma unroll
     for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + rs[e];
     if (!st) return;
-    if (p.out_f32) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + (long)m * p.ldc + n, v);
-    else           storev<W>(reinterpret_cast<bf16*>(p.C) + (long)m * p.ldc + n, v);
+    if (f32o) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + coff, v);
+    else      storev<W>(reinterpret_cast<bf16*>(p.C) + coff, v);
+}
+template <int W, int ACT = -1>
+__device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W], const float (&bs)[W], const float (&ax)[W],
+                                               const float (&rs)[W], int m, int n, int split) {
+    epi_math_store_at<W, ACT, -1>(p, v, bs, ax, rs, (long)m * p.ldc + n, (long)m * p.ldpre + n, split);
 }
 template <int W> __device__ __forceinline__ void epi_apply(const GemmParams& p, float (&v)[W], const EpiIn<W>& in, int m, int n, int split) {
     float bs[W];
