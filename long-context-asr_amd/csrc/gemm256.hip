@@ -171,6 +171,41 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
         for (int e = 0; e < WH; ++e) bhi[e] = 0.f;
         if (FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
         const long crow0 = (long)mbase * p.ldc, prow0 = (long)mbase * p.ldpre;      // per-lane row offsets; the rest is wave-uniform
+        if constexpr (FL >= 0 && (RES || ACT == SCONF_ACT_MULAUX)) {
+            // Software-pipelined over the 8 row blocks: the residual / aux loads of block rb + AH are issued BEFORE the math and
+            // stores of block rb, so by the time they are needed the stores they queue behind (block rb - 1's and older) have
+            // long drained.  (Loading each pair of blocks right after the previous pair's stores made every pair wait for a full
+            // store round trip: 38-41 k cycles for an f32 + residual tile against ~8 k for a bf16 one.)
+            constexpr int NB = 8, AH = JH == 2 ? 1 : 2;      // prefetch depth in row blocks: what the VGPR budget allows without spills
+            float rl[AH + 1][8], rh[AH + 1][WH];
+            typename RawBf<8>::type xl[AH + 1];
+            typename RawBf<WH>::type xh[AH + 1];
+            auto fetch = [&](int rb, int slot) {
+                const int row = mbase + 128 * (rb >> 2) + 16 * (rb & 3);
+                if constexpr (RES) { const float* q = p.resid + (long)row * p.ldr; loadv<8>(q + nlo, rl[slot]); loadv<WH>(q + nhi, rh[slot]); }
+                if constexpr (AUX) {
+                    const bf16* q = p.aux + (long)row * p.ldaux;
+                    xl[slot] = *reinterpret_cast<const typename RawBf<8>::type*>(q + nlo);
+                    xh[slot] = *reinterpret_cast<const typename RawBf<WH>::type*>(q + nhi);
+                }
+            };
+#pragma unroll
+            for (int rb = 0; rb < AH; ++rb) fetch(rb, rb);
+#pragma unroll
+            for (int rb = 0; rb < NB; ++rb) {
+                if (rb + AH < NB) fetch(rb + AH, (rb + AH) % (AH + 1));
+                const int h = rb >> 2, i = rb & 3, sl = rb % (AH + 1);
+                float vlo[8], vhi[WH], alo[8], ahi[WH], zlo[8], zhi[WH];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)xl[sl][e] : 0.f; zlo[e] = RES ? rl[sl][e] : 0.f; }
+#pragma unroll
+                for (int e = 0; e < WH; ++e) { vhi[e] = acc[h][i][2 + (e >> 2)][e & 3]; ahi[e] = AUX ? (float)xh[sl][e] : 0.f; zhi[e] = RES ? rh[sl][e] : 0.f; }
+                const long crow = crow0 + (long)(128 * h + 16 * i) * p.ldc, prow = prow0 + (long)(128 * h + 16 * i) * p.ldpre;
+                epi_math_store_at<8, ACT, FL>(p, vlo, blo, alo, zlo, crow + nlo, prow + nlo, it.split);
+                epi_math_store_at<WH, ACT, FL>(p, vhi, bhi, ahi, zhi, crow + nhi, prow + nhi, it.split);
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             typename RawBf<8>::type axlo[4];

@@ -105,6 +105,15 @@ __device__ __forceinline__ void epi_math_store_at(const GemmParams& p, float (&v
     if (f32o) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + coff, v);
     else      storev<W>(reinterpret_cast<bf16*>(p.C) + coff, v);
 }
+// Store-only step of a two-phase epilogue: v already holds resid + alpha * act(acc + bias).
+template <int W, int FL>
+__device__ __forceinline__ void epi_store_at(const GemmParams& p, const float (&v)[W], long coff, int split) {
+#ifdef SCONF_GEMM_PROBE
+    if (p.debug == 1 && v[0] != 1.2345e-30f) return;
+#endif
+    if ((FL & 2) != 0) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + coff, v);
+    else               storev<W>(reinterpret_cast<bf16*>(p.C) + coff, v);
+}
 template <int W, int ACT = -1>
 __device__ __forceinline__ void epi_math_store(const GemmParams& p, float (&v)[W], const float (&bs)[W], const float (&ax)[W],
                                                const float (&rs)[W], int m, int n, int split) {
