@@ -172,14 +172,14 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
         if (FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
         const long crow0 = (long)mbase * p.ldc, prow0 = (long)mbase * p.ldpre;      // per-lane row offsets; the rest is wave-uniform
         if constexpr (FL >= 0 && (RES || ACT == SCONF_ACT_MULAUX)) {
-            // Software-pipelined over the 8 row blocks: the residual / aux loads of block rb + AH are issued BEFORE the math and
-            // stores of block rb, so by the time they are needed the stores they queue behind (block rb - 1's and older) have
-            // long drained.  (Loading each pair of blocks right after the previous pair's stores made every pair wait for a full
+            // Software-pipelined over the 8 row blocks: residual / aux loads are issued blocks ahead of the math and stores that
+            // use them, so by the time they are needed the stores they queue behind have long drained.  (Loading each pair of blocks right after the previous pair's stores made every pair wait for a full
             // store round trip: 38-41 k cycles for an f32 + residual tile against ~8 k for a bf16 one.)
-            constexpr int NB = 8, AH = JH == 2 ? 1 : 2;      // prefetch depth in row blocks: what the VGPR budget allows without spills
-            float rl[AH + 1][8], rh[AH + 1][WH];
-            typename RawBf<8>::type xl[AH + 1];
-            typename RawBf<WH>::type xh[AH + 1];
+            constexpr int NB = 8;                             // row blocks
+            constexpr int NS = RES ? (JH == 2 ? 2 : 3) : 5;   // register slots for blocks in flight (f32 residual: 16 VGPRs per block, aux: 8)
+            float rl[NS][8], rh[NS][WH];
+            typename RawBf<8>::type xl[NS];
+            typename RawBf<WH>::type xh[NS];
             auto fetch = [&](int rb, int slot) {
                 const int row = mbase + 128 * (rb >> 2) + 16 * (rb & 3);
                 if constexpr (RES) { const float* q = p.resid + (long)row * p.ldr; loadv<8>(q + nlo, rl[slot]); loadv<WH>(q + nhi, rh[slot]); }
@@ -190,11 +190,19 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
                 }
             };
 #pragma unroll
-            for (int rb = 0; rb < AH; ++rb) fetch(rb, rb);
+            for (int nb = 0; nb < (RES ? NS - 1 : 1); ++nb) fetch(nb, nb);
+            // Aux tiles (bf16, 8 VGPRs per block): the look-ahead GROWS - blocks 1 | 2,3 | 4,5 | 6,7 are requested before blocks
+            // 0 | 1 | 2 | 3 are processed, so after the first two round trips every remaining load is already in flight (one block
+            // ahead throughout left 8 exposed round trips: 25 k cycles for the aux tile of an FF dgrad item).
 #pragma unroll
             for (int rb = 0; rb < NB; ++rb) {
-                if (rb + AH < NB) fetch(rb + AH, (rb + AH) % (AH + 1));
-                const int h = rb >> 2, i = rb & 3, sl = rb % (AH + 1);
+                {
+                    // residual (arch-VGPR bound): fixed look-ahead of NS - 1 blocks; aux only: the growing schedule
+                    const int lo_b = RES ? rb + NS - 1 : (rb == 0 ? 1 : 2 * rb), hi_b = RES ? rb + NS - 1 : 2 * rb + 1;
+#pragma unroll
+                    for (int nb = lo_b; nb <= hi_b; ++nb) if (nb < NB) fetch(nb, nb % NS);
+                }
+                const int h = rb >> 2, i = rb & 3, sl = rb % NS;
                 float vlo[8], vhi[WH], alo[8], ahi[WH], zlo[8], zhi[WH];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)xl[sl][e] : 0.f; zlo[e] = RES ? rl[sl][e] : 0.f; }

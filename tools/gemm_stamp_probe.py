@@ -9,7 +9,7 @@ from lcasr_amd.hip import _lib
 lib = _lib.load()
 lib.sconf_gemm_probe_stamps.argtypes = [ctypes.c_void_p]
 M = 131072
-cases = {'gelu_dsave': (3072, 768, dict(act='gelu_dsave', save_pre=True, bias=True)), 'plain': (3072, 768, {}),
+cases = {'gelu_dsave': (3072, 768, dict(act='gelu_dsave', save_pre=True)), 'plain': (3072, 768, {}), 'mulaux': (3072, 768, dict(act='mulaux', aux=True)), 'bias': (1536, 768, dict(bias=True)),
          'f32res768': (768, 768, dict(resid=True, out_dtype=torch.float32))}
 for name in sys.argv[1:] or ['gelu_dsave', 'plain']:
     n, k, kw = cases[name]
@@ -17,8 +17,9 @@ for name in sys.argv[1:] or ['gelu_dsave', 'plain']:
     kw = dict(kw)
     if kw.get('bias'): kw['bias'] = torch.randn(n, device='cuda')
     if kw.get('resid'): kw['resid'] = torch.randn(M, n, device='cuda')
+    if kw.get('aux'): kw['aux'] = torch.randn(M, n, device='cuda').bfloat16()
     os.environ['SCONF_GEMM_256_WIDTH'] = '256'
-    for stagger, mode in ((0, 0), (8, 0), (8, 1), (8, 2)):
+    for stagger, mode in ((0, 0), (8, 1)):
         os.environ['SCONF_GEMM_STAGGER'] = str(stagger); os.environ['SCONF_GEMM_STAGGER_MODE'] = str(mode)
         st = torch.zeros(256, 64, 4, dtype=torch.int64, device='cuda')
         for _ in range(3): ops.gemm(a, b, 'nt', **kw)
