@@ -89,6 +89,17 @@ __device__ __forceinline__ void dma_half(const char* base, const unsigned (&off)
         __builtin_amdgcn_global_load_lds((gptr)(base + off[i]), (lptr)(dst + ((tid & ~63) + 512 * i) * 16), 16, 0, 0);
 }
 
+// Transposed LDS read as inline asm.  Through the builtin, hipcc puts an unconditional `s_waitcnt vmcnt(0)` in front of the
+// reads (it cannot tell them from the in-flight LDS-DMA destinations), which drains the whole prefetch pipeline twice per
+// K-tile - the reason the K-strided (weight-gradient) kernel sat parked 57 % of its wave-cycles.  The asm form is invisible to
+// that logic AND to the compiler's lgkmcnt tracking: the consumer must run LGKM_FENCE (wait + register tie) before using it.
+__device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(unsigned long)(lptr)p));
+    return v;
+}
+#define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define TIE(x) asm volatile("" : "+v"(x))
 // 16 x 32 MFMA fragments.  K-contiguous: one ds_read_b128; K-strided ([64 k][128 cols] image): two transposed reads.
 template <bool KS> __device__ __forceinline__ bf16x8 frag_a(const char* s, int wr, int i, int kk, int lane) {
     if (!KS) {
@@ -98,8 +109,8 @@ template <bool KS> __device__ __forceinline__ bf16x8 frag_a(const char* s, int w
         const int a = lane & 15, q = a >> 2, pp = a & 3, g = lane >> 4;
         const int col = 64 * wr + 16 * i + 4 * pp, chunk = col >> 3, sub = (col & 4) * 2;
         const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub));
+        bf16x4 lo = lds_read_tr(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub);
+        bf16x4 hi = lds_read_tr(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -117,8 +128,8 @@ template <bool KS, bool NARROW> __device__ __forceinline__ bf16x8 frag_b(const c
         const int a = lane & 15, q = a >> 2, pp = a & 3, g = lane >> 4;
         const int col = 32 * wc + 16 * j + 4 * pp, chunk = col >> 3, sub = (col & 4) * 2;
         const int k0 = kk * 32 + 8 * g + q, k1 = k0 + 4;
-        bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub));
-        bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p4)(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub));
+        bf16x4 lo = lds_read_tr(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub);
+        bf16x4 hi = lds_read_tr(s + k1 * 256 + ((chunk ^ swz_strided(k1)) << 4) + sub);
         return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
     }
 }
@@ -386,6 +397,16 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             issue_b(pc, 1);
             wait_window<JH>(pc.valid);
             __builtin_amdgcn_s_barrier();
+            if constexpr (KS) {
+                LGKM0();
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) TIE(blo[j][kk]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) TIE(fa[i][kk]);
+                }
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -404,6 +425,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             issue_a(pc, 1);
             wait_window<JH>(pc.valid);
             __builtin_amdgcn_s_barrier();
+            if constexpr (KS) {
+                LGKM0();
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int j = 0; j < JH; ++j) TIE(bhi[j][kk]);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -423,6 +451,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             issue_a(pc, 0);
             wait_window<JH>(pc.valid);
             __builtin_amdgcn_s_barrier();
+            if constexpr (KS) {
+                LGKM0();
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) TIE(fa[i][kk]);
+            }
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
