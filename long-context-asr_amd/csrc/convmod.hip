@@ -184,11 +184,12 @@ __global__ __launch_bounds__(256) void brn_bwd_reduce_kernel(const bf16* __restr
     for (long r = r0; r < r1; r += 4) {                      // 4 rows of loads in flight per thread
         float g[4][CV], x[4][CV];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (r + u < r1) { load4(dy + (r + u) * d + c0, g[u]); load4(h + (r + u) * d + c0, x[u]); }
-            else {
+        for (int u = 0; u < 4; ++u) {            // unconditional loads (row clamped, gradient zeroed past the end): a load under a
+            const long rr = min(r + u, r1 - 1);  // run-time test is branched around and waited for on its own (vmcnt(0) per row)
+            load4(dy + rr * d + c0, g[u]); load4(h + rr * d + c0, x[u]);
+            if (r + u >= r1) {
 #pragma unroll
-                for (int e = 0; e < CV; ++e) { g[u][e] = 0.f; x[u][e] = mean[e]; }
+                for (int e = 0; e < CV; ++e) g[u][e] = 0.f;
             }
         }
 #pragma unroll

@@ -88,6 +88,16 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const bf16* __restric
         const int p = (blockIdx.x * iters + it) * PL + g.plane;
         if (p >= npos) break;
         const int to = p / Fo, fo = p - to * Fo;
+        // All nine tap loads are issued unconditionally (address clamped into the image, contribution zeroed afterwards): a
+        // load under a run-time bounds test makes hipcc branch around it and wait vmcnt(0) per tap - nine dependent round trips.
+        bf16x8 raw[9];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = min(max(2 * to + i - 1, 0), Ti - 1), f = min(max(2 * fo + j - 1, 0), Fi - 1);
+                raw[i * 3 + j] = *reinterpret_cast<const bf16x8*>(xb + ((long)t * Fi + f) * C);
+            }
         float acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[e] = bs[e];
@@ -96,11 +106,9 @@ __global__ __launch_bounds__(256) void dwconv2d_fwd_kernel(const bf16* __restric
 #pragma unroll
             for (int j = 0; j < 3; ++j) {
                 const int t = 2 * to + i - 1, f = 2 * fo + j - 1;
-                if (t >= 0 && t < Ti && f >= 0 && f < Fi) {
-                    float v[8]; load8(xb + ((long)t * Fi + f) * C, v);
+                const float in = (t >= 0 && t < Ti && f >= 0 && f < Fi) ? 1.f : 0.f;
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += wk[i * 3 + j][e] * siluf_(v[e]);
-                }
+                for (int e = 0; e < 8; ++e) acc[e] += wk[i * 3 + j][e] * (in * siluf_((float)raw[i * 3 + j][e]));
             }
         store8(yb + (long)p * C, acc);
     }
@@ -136,6 +144,18 @@ __global__ __launch_bounds__(512) void dwconv2d_bwd_kernel(const bf16* __restric
             const int p = (blockIdx.x * iters + it) * PL + g.plane;
             if (p >= npos) break;
             const int ti = p / Fi, fi = p - ti * Fi;
+            // The (up to) four output gradients this input position feeds sit at (to0 - a, fo0 - b), a, b in {0, 1}, with
+            // to0 = (ti + 1) / 2, fo0 = (fi + 1) / 2 (a = 1 only for odd ti: tap row 2; a = 0 is tap row 0 or 1).  All four
+            // are loaded up front with clamped addresses - a load under each tap's run-time test cost a round trip per tap.
+            const int to0 = (ti + 1) >> 1, fo0 = (fi + 1) >> 1;
+            float gq[2][2][CW];
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int bb = 0; bb < 2; ++bb) {
+                    const int to = min(max(to0 - a, 0), To - 1), fo = min(max(fo0 - bb, 0), Fo - 1);
+                    gemm_free_loadv<CW>(gb + ((long)to * Fo + fo) * C, gq[a][bb]);
+                }
             float pv[CW], sg[CW], sv[CW]; gemm_free_loadv<CW>(pb + (long)p * C, pv);
 #pragma unroll
             for (int e = 0; e < CW; ++e) { sg[e] = sigmoidf_(pv[e]); sv[e] = pv[e] * sg[e]; }
@@ -154,7 +174,7 @@ __global__ __launch_bounds__(512) void dwconv2d_bwd_kernel(const bf16* __restric
                     if (ff < 0 || (ff & 1)) continue;
                     const int fo = ff >> 1;
                     if (fo >= Fo) continue;
-                    float gv[CW]; gemm_free_loadv<CW>(gb + ((long)to * Fo + fo) * C, gv);
+                    const float (&gv)[CW] = gq[i == 2][j == 2];            // (to, fo) = (to0 - (i == 2), fo0 - (j == 2))
 #pragma unroll
                     for (int e = 0; e < CW; ++e) {
                         acc[e] += wk[i * 3 + j][e] * gv[e];
@@ -562,11 +582,11 @@ SCONF_API int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void*
     SUB_REQ("sconf_sub_dwconv_bwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
     if (B * Ti * Fi == 0) return 0;
-    long target = 512; int cw = 4;                             // few, fat (512-thread) workgroups: each ends with 10 x C atomics
+    long target = 512; int cw = 8;                             // few workgroups (each ends with 10 x C atomics), 16-B accesses
     if (const char* e = getenv("SCONF_SUB_DWBWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { cw = a; target = t; } }   // tuning
     const int cgs = (int)(C / cw);
     SCONF_REQUIRE(cgs <= 256, "sconf_sub_dwconv_bwd: C too large");
-    int nthr = 512;
+    int nthr = 256;                                            // measured with all tap loads in flight: 3.3 -> 1.9 ms at B = 64
     if (const char* e = getenv("SCONF_SUB_DWBWD_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512) nthr = v; }     // tuning
     const int PL = std::max(1, nthr / cgs), threads = (cgs * PL + 63) / 64 * 64;
     const long npos = (long)Ti * Fi, per_b = std::max<long>(1, target / B);

@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import lcasr_amd.hip.ops as ops
-B, F, T, C = 16, 80, 16384, 256
+B, F, T, C = int(os.environ.get("SUB_B", "16")), 80, 16384, 256
 x = torch.randn(B, F, T, device='cuda')
 w0 = torch.randn(C, 9, device='cuda') * 0.3; b0 = torch.randn(C, device='cuda') * 0.1
 wd = torch.randn(C, 9, device='cuda') * 0.3; bd = torch.randn(C, device='cuda') * 0.1
@@ -30,6 +30,6 @@ gw, gbv = torch.zeros(C, 9, device='cuda'), torch.zeros(C, device='cuda')
 print(f'dwconv fwd: {t(lambda: ops.sub_dwconv_fwd(pre1, wd, bd)):.3f} ms')
 for thr in ('256', '512'):
     os.environ['SCONF_SUB_DWBWD_THREADS'] = thr
-    for cfg in ('4,512', '4,1024', '4,2048', '8,512', '8,1024'):
+    for cfg in ('4,512', '4,1024', '8,256', '8,512', '8,1024', '8,2048'):
         os.environ['SCONF_SUB_DWBWD_CFG'] = cfg
         print(f'dwconv bwd threads {thr} cfg {cfg}: {t(lambda: ops.sub_dwconv_bwd(dd2, wd, pre1, gw, gbv)):.3f} ms')
