@@ -317,7 +317,8 @@ __device__ __forceinline__ void stage_mel(const TX* __restrict__ xb, float* xs, 
     __syncthreads();
     for (int idx = threadIdx.x; idx < NT * F; idx += 256) {
         const int f = idx / NT, tt = idx - f * NT, t = t_base + tt;
-        xs[tt * F + f] = (t >= 0 && t < T) ? ld_f(xb + (long)f * T + t) : 0.f;
+        const float v = ld_f(xb + (long)f * T + min(max(t, 0), T - 1));        // unconditional (clamped) load: no branch, no
+        xs[tt * F + f] = (t >= 0 && t < T) ? v : 0.f;                          // per-element vmcnt(0); zero padding applied after
     }
     __syncthreads();
 }
@@ -381,7 +382,8 @@ __global__ __launch_bounds__(512) void stage01_fwd_kernel(const TX* __restrict__
         __syncthreads();                                       // previous dw phase done with the window + mel patch
         for (int idx = threadIdx.x; idx < 7 * F; idx += blockDim.x) {
             const int f = idx / 7, tt = idx - f * 7, t = 4 * t4 - 3 + tt;
-            if (tt >= (first ? 0 : 2)) xs[tt * F + f] = (t >= 0 && t < T) ? ld_f(xb + (long)f * T + t) : 0.f;
+            const float v = ld_f(xb + (long)f * T + min(max(t, 0), T - 1));             // unconditional (clamped) load
+            if (tt >= (first ? 0 : 2)) xs[tt * F + f] = (t >= 0 && t < T) ? v : 0.f;
         }
         __syncthreads();
         if (g.active) {
@@ -478,8 +480,8 @@ __global__ __launch_bounds__(256) void stage01_bwd_kernel(const TX* __restrict__
         const int to0 = (tb - 1) >> 1;                     // first dd1 row any of the rows tb .. tb+RW-1 can feed (may be -1)
         for (int idx = threadIdx.x * 8; idx < NG * rowel; idx += 256 * 8) {
             const int slot = idx / rowel, to = to0 + slot;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (to >= 0 && to < T4) v = *reinterpret_cast<const uint4*>(gp + (long)to * rowel + (idx - slot * rowel));
+            uint4 v = *reinterpret_cast<const uint4*>(gp + (long)min(max(to, 0), T4 - 1) * rowel + (idx - slot * rowel));   // clamped,
+            if (to < 0 || to >= T4) v = make_uint4(0, 0, 0, 0);                                                             // unconditional
             *reinterpret_cast<uint4*>(grow + idx) = v;
         }
         __syncthreads();
@@ -634,7 +636,7 @@ SCONF_API int sconf_sub_stage01_fwd(const void* x, int x_dtype, const float* w0,
     SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_fwd: B <= 65535 and F <= 1024");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
     if (B * T4 * F4 == 0) return 0;
-    long target = 2048;
+    long target = 4096;
     if (const char* e = getenv("SCONF_SUB_FWD_BLOCKS")) target = atol(e);                       // tuning
     const int rpb = std::max(1, (int)cdiv((long)T4 * B, target));
     dim3 grid(cdiv(T4, rpb), (unsigned)B), block(512);           // 8 waves: two workgroups (LDS-limited) fill a CU's 16 wave slots
