@@ -98,6 +98,23 @@ __device__ __forceinline__ bf16x4 lds_read_tr(const char* p) {
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((unsigned)(unsigned long)(lptr)p));
     return v;
 }
+template <int OFF> __device__ __forceinline__ bf16x4 lds_read_tr_off(unsigned a) {
+    bf16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(a), "n"(OFF));
+    return v;
+}
+// Both k-steps' fragments of one 16-wide block of a K-strided image from ONE per-lane base address: k-step 1 is +32 k-rows
+// (8192 B) and the second half of each fragment +4 k-rows (1024 B); the XOR swizzle depends on (k & 3, (k >> 3) & 1), which
+// those offsets leave unchanged, so all four reads are base + immediate.
+__device__ __forceinline__ void frag_pair_ks(const char* s, int col, int lane, bf16x8& f0, bf16x8& f1) {
+    const int a = lane & 15, q = a >> 2, g = lane >> 4;
+    const int chunk = col >> 3, sub = (col & 4) * 2, k0 = 8 * g + q;
+    const unsigned base = (unsigned)(unsigned long)(lptr)(s + k0 * 256 + ((chunk ^ swz_strided(k0)) << 4) + sub);
+    const bf16x4 l0 = lds_read_tr_off<0>(base), h0 = lds_read_tr_off<1024>(base);
+    const bf16x4 l1 = lds_read_tr_off<8192>(base), h1 = lds_read_tr_off<9216>(base);
+    f0 = __builtin_shufflevector(l0, h0, 0, 1, 2, 3, 4, 5, 6, 7);
+    f1 = __builtin_shufflevector(l1, h1, 0, 1, 2, 3, 4, 5, 6, 7);
+}
 #define LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #define TIE(x) asm volatile("" : "+v"(x))
 // 16 x 32 MFMA fragments.  K-contiguous: one ds_read_b128; K-strided ([64 k][128 cols] image): two transposed reads.
@@ -387,13 +404,21 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             const bool last = kt == cit.nkt - 1;
             // ---- q0: B-lo, A-lo -> acc[0][.][0..1] ---------------------------------------------------------------
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (KS) frag_pair_ks(buf + 2 * HT, 32 * wc + 16 * j + 4 * (lane & 3), lane, blo[j][0], blo[j][1]);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) blo[j][kk] = frag_b<KS, false>(buf + 2 * HT, wc, j, kk, lane);
+                    for (int kk = 0; kk < 2; ++kk) blo[j][kk] = frag_b<KS, false>(buf + 2 * HT, wc, j, kk, lane);
+                }
+            }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (KS) frag_pair_ks(buf, 64 * wr + 16 * i + 4 * (lane & 3), lane, fa[i][0], fa[i][1]);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf, wr, i, kk, lane);
+                    for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf, wr, i, kk, lane);
+                }
+            }
             issue_b(pc, 1);
             wait_window<JH>(pc.valid);
             __builtin_amdgcn_s_barrier();
@@ -419,9 +444,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             __builtin_amdgcn_s_barrier();
             // ---- q1: B-hi -> acc[0][.][2..3] ---------------------------------------------------------------------
 #pragma unroll
-            for (int j = 0; j < JH; ++j)
+            for (int j = 0; j < JH; ++j) {
+                if constexpr (KS) frag_pair_ks(buf + 3 * HT, 32 * wc + 16 * j + 4 * (lane & 3), lane, bhi[j][0], bhi[j][1]);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) bhi[j][kk] = frag_b<KS, JH == 1>(buf + 3 * HT, wc, j, kk, lane);
+                    for (int kk = 0; kk < 2; ++kk) bhi[j][kk] = frag_b<KS, JH == 1>(buf + 3 * HT, wc, j, kk, lane);
+                }
+            }
             issue_a(pc, 1);
             wait_window<JH>(pc.valid);
             __builtin_amdgcn_s_barrier();
@@ -444,9 +473,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
             __builtin_amdgcn_s_barrier();
             // ---- q2: A-hi -> acc[1][.][2..3] ---------------------------------------------------------------------
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < 4; ++i) {
+                if constexpr (KS) frag_pair_ks(buf + HT, 64 * wr + 16 * i + 4 * (lane & 3), lane, fa[i][0], fa[i][1]);
+                else {
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf + HT, wr, i, kk, lane);
+                    for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf + HT, wr, i, kk, lane);
+                }
+            }
             pc.advance(p, sc);
             issue_a(pc, 0);
             wait_window<JH>(pc.valid);
