@@ -26,11 +26,13 @@ CONFIGS = {
     # BASELINE.json configs[2]: the configuration the metric is quoted on
     'c3': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
-                          default_norm='layer_norm', bias_in_ff=False), T=16384, batch=64,
+                          default_norm='layer_norm', bias_in_ff=False), T=16384, batch=128,
                # per-GPU batch: the reference trains this length with 22 recordings per 80 GB GPU (exp/configs/16_ds.yaml:92,
-               # constant 360 k frames per batch); 64 is the same fill of 288 GB (~60 GB of activations) and the most efficient
-               # size measured here (frames/s at B = 16 / 32 / 64 / 128: 5.00 / 5.30 / 5.50 / 5.59 M; above 64 the largest stage
-               # tensor passes 2^31 elements, so 64 it is)
+               # constant 360 k frames per batch) = 79 per 288 GB; the batch sizes that give every GEMM whole rounds of 256x256
+               # tiles are multiples of 64, and 128 (131 GiB peak) is the faster of the two that fit comfortably: frames/s at
+               # B = 16 / 32 / 64 / 96 / 128 on the v11 kernels ~ 5.3 / 5.6 / 5.96 / 5.7 / 6.08 M.  At 128 the subsampler's stage-1
+               # tensors pass 2^31 elements; tests/test_model_gpu.py::test_subsampler_over_2pow31_elements_matches_two_halves
+               # pins the 64-bit offsets.
                name='6L/768D/6H SConformerXL, seq=16384, rotary theta=1.5M'),
     'c2': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
@@ -119,10 +121,10 @@ class GemmTimer:
         # correction, see the file's header); the operand / output bytes of the same launches are computed here
         traffic, src = None, None
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_v10.json')))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_v12.json')))
             key = GEMM_KERNELS.get(top, '').split(' (')[0]
             if key in tj['kernels']:
-                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r01_hbm_traffic_v10.json (PMC, B=64 run)'
+                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r01_hbm_traffic_v12.json (PMC, same batch)'
         except Exception:
             pass
         return dict(bound='mfma', kernel=GEMM_KERNELS.get(top, str(top)), achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,

@@ -211,3 +211,37 @@ def test_train_recording_chunked_ragged_shrinking_batch():
     cfg = O.make_config(**golden_cfg(fx))
     oloss, _, _ = O.train_step_loss(sd0, cfg, audio[:, :, :256], torch.tensor(seen[0][3]), seen[0][4], seen[0][5])
     assert abs(float(losses[0]) - float(oloss)) / float(oloss) < 3e-3, (float(losses[0]), float(oloss))
+
+
+def test_subsampler_over_2pow31_elements_matches_two_halves():
+    """At 128 x 16384-frame samples the stage-1 tensors of the subsampler hold 2.7e9 elements (> 2^31): every offset that
+    spans samples must be 64-bit.  The subsampler has no cross-sample operation, so the full batch must reproduce the two
+    halves: outputs row for row, parameter gradients as their sum."""
+    import lcasr_amd.functional as Fn
+    from lcasr_amd.components.subsampling import ConvSubsampling
+    torch.manual_seed(3)
+    sub = ConvSubsampling(subsampling='dw_striding', conv_channels=256, activation=torch.nn.SiLU(), subsampling_factor=8, feat_in=80,
+                          feat_out=768, norm_out=False).cuda()
+    B, T = 128, 16384
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(B, T, 80, generator=g).cuda()                                   # (B, T, F) as ConvSubsampling.forward takes it
+    gy = (torch.randn(B, T // 8, 768, generator=g) * 0.1).cuda()
+    lengths = torch.full((B,), T, device='cuda')
+
+    def run(sl):
+        for p in sub.parameters(): p.grad = None
+        Fn.refresh_weight_shadows()
+        y, _ = sub(x[sl], lengths=lengths[sl])
+        y.backward(gy[sl])
+        torch.cuda.synchronize()
+        return y.detach(), [p.grad.detach().clone() for p in sub.parameters()]
+
+    y_full, g_full = run(slice(0, B))
+    assert y_full.numel() * 0 == 0 and torch.isfinite(y_full).all()
+    y_a, g_a = run(slice(0, B // 2))
+    y_b, g_b = run(slice(B // 2, B))
+    assert torch.equal(y_full[:B // 2], y_a) and torch.equal(y_full[B // 2:], y_b)          # no cross-sample arithmetic at all
+    for (n, _), gf, ga, gb in zip(sub.named_parameters(), g_full, g_a, g_b):
+        ref = ga.double() + gb.double()
+        err = float((gf.double() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        assert err < 2e-3, (n, err)                                                           # split-K / atomic order only
