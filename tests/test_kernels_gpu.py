@@ -512,3 +512,25 @@ def test_overlap_average_and_argmax(ops):
     x = torch.randn(1001, 4096)
     x[5, 100] = x[5, 3000] = 9.0; x[6] = 0.0                   # ties: first index wins
     assert torch.equal(ops.argmax_rows(dev(x)).cpu(), R.argmax_rows(x))
+
+
+@pytest.mark.parametrize('K', [64, 128, 192, 320])
+def test_gemm_256_row_kernels_short_k(ops, K, monkeypatch):
+    """1, 2, 3 and 5 K-tiles per work item: the prologue, the item-crossing prefetch cursor and the drained tail of the
+    256-row kernels (NT with plain loads, TN with the inline-asm transposed reads and hand-placed waits) with almost no
+    steady state in between.  Bit-identical to the 128x128 kernel."""
+    M = N = 4096
+    monkeypatch.delenv('SCONF_GEMM_NO_256', raising=False)
+    g = torch.Generator().manual_seed(K)
+    for layout in ('nt', 'tn'):
+        if _variant(ops, layout, M, N, K) == 0:
+            pytest.skip('shape not routed to the 256-row kernels')
+        a = (torch.randn(*((M, K) if layout == 'nt' else (K, M)), generator=g) * 0.5).to(BF).cuda()
+        b = (torch.randn(*((N, K) if layout == 'nt' else (K, N)), generator=g) * 0.5).to(BF).cuda()
+        new = ops.gemm(a, b, layout, out_dtype=F32)
+        monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
+        old = ops.gemm(a, b, layout, out_dtype=F32)
+        monkeypatch.delenv('SCONF_GEMM_NO_256')
+        assert torch.equal(new, old), (layout, K)
+        ref = (a.float() @ b.float().t()) if layout == 'nt' else (a.float().t() @ b.float())
+        assert float((new - ref).abs().max()) <= 1e-5 * float(ref.abs().max()) + 1e-6
