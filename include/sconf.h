@@ -155,9 +155,14 @@ int sconf_argmax_rows(const float* x, int64_t M, int64_t C, int32_t* idx, sconf_
 
 /* Fused MADGRAD + global-norm clip over flat f32 buffers (lcasr/optim/madgrad.py:81-212, exp/train.py:46-61). */
 int sconf_sumsq(const float* g, int64_t n, double* out, sconf_stream_t stream);
-int sconf_madgrad_step(float* p, const float* g, float* grad_sum_sq, float* s, const float* x0, void* bf16_shadow,
+/* k = steps applied so far: from the host, or read from k_dev (device int64) when k_dev != NULL.  At k == 0 the kernel creates
+ * x0 := p (the reference creates its state lazily at the first step, madgrad.py:121-125).  A step whose gradient norm is not
+ * finite is skipped; sconf_madgrad_advance (once per optimiser step, after the per-group launches) then leaves *k_dev alone,
+ * as GradScaler.step skips optimizer.step() in exp/train.py:54-57. */
+int sconf_madgrad_step(float* p, const float* g, float* grad_sum_sq, float* s, float* x0, void* bf16_shadow,
                        int64_t n, const double* sumsq, float max_norm, float grad_scale, float lr, float momentum,
-                       float eps, float weight_decay, int64_t k, sconf_stream_t stream);
+                       float eps, float weight_decay, int64_t k, const int64_t* k_dev, sconf_stream_t stream);
+int sconf_madgrad_advance(int64_t* k_dev, const double* sumsq, float grad_scale, sconf_stream_t stream);
 
 #ifdef __cplusplus
 }

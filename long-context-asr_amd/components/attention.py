@@ -32,11 +32,36 @@ class Attention(nn.Module):
         self.out_proj = nn.Linear(n_heads * head_dim, n_feats, bias=kwargs.get('bias', False))
 
     def forward_prenorm(self, x, norm, residual, lengths=None, rotary=None, **_):
-        """x (B,N,d) f32.  lengths: int32 (B,) device tensor or None.  rotary: (cos, sin) compact tables or None."""
+        """x (B,N,d) f32.  lengths: int32 (B,) device tensor or None.  rotary: (cos, sin) compact tables or None.
+        norm None: x is already normalised (the module-level `forward`)."""
         B, N, _d = x.shape
-        nw, nb = norm.norm_params()
+        nw, nb = norm.norm_params() if norm is not None else (None, None)
+        mode, eps = (norm.mode, norm.eps) if norm is not None else ('none', 0.0)
         cos, sin = rotary if rotary is not None else (None, None)
         y = Fn.attn_block(x.reshape(B * N, -1), nw, nb, self.qkv_proj.weight, self.out_proj.weight, self.qkv_proj.bias,
                           self.out_proj.bias, cos, sin, lengths, B, N, self.n_heads, self.head_dim,
-                          (self.left_window, self.right_window), norm.mode, norm.eps, residual)
+                          (self.left_window, self.right_window), mode, eps, residual)
         return y.view(B, N, -1)
+
+    def forward(self, x, attn_mask=None, length=None, pad_mask=None, flash_attn=True, rotary_emb_fn=None):
+        """The reference's module-level call (attention.py:509-551) on an already normalised x (B,N,d).
+        pad_mask (B,N) bool, True = padded position: must be the suffix mask sconformer_xl.py:207 builds from `length`;
+        attn_mask carries the same information in the reference and is ignored here.  rotary_emb_fn: the reference's
+        `apply_rotary` object (.cos/.sin of shape (1,n,1,D)) or a (cos, sin) pair of compact (n, D/2) tables."""
+        import torch
+        B, N, _d = x.shape
+        lengths = None
+        if pad_mask is not None:
+            lengths = (~pad_mask).sum(-1).to(dtype=torch.int32).contiguous()
+        elif length is not None and int(length.max()) != int(length.min()):
+            lengths = length.to(device=x.device, dtype=torch.int32).contiguous()
+        rotary = None
+        if rotary_emb_fn is not None:
+            if isinstance(rotary_emb_fn, (tuple, list)):
+                rotary = tuple(rotary_emb_fn)
+            else:
+                if getattr(rotary_emb_fn, 'learned', False):
+                    raise NotImplementedError('learned rotary frequencies are not on the hot path')
+                h = self.head_dim // 2
+                rotary = (rotary_emb_fn.cos[0, :N, 0, :h].float().contiguous(), rotary_emb_fn.sin[0, :N, 0, :h].float().contiguous())
+        return self.forward_prenorm(x, None, False, lengths=lengths, rotary=rotary)

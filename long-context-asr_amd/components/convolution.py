@@ -26,12 +26,21 @@ class ConformerConvolution(nn.Module):
         self.use_fft_conv = False
         self.pointwise_conv2 = nn.Conv1d(inner_dim, d_model, kernel_size=1, stride=1, padding=0, bias=True)
 
+    def forward(self, x, pad_mask=None, **kwargs):
+        """The reference's module-level call (convolution.py:103-124) on an already normalised x (B,N,d); pad_mask (B,N) bool,
+        True = padded (the suffix mask of sconformer_xl.py:207)."""
+        import torch
+        lengths = None if pad_mask is None else (~pad_mask).sum(-1).to(dtype=torch.int32).contiguous()
+        return self.forward_prenorm(x, None, False, lengths=lengths)
+
     def forward_prenorm(self, x, norm, residual, lengths=None, **_):
+        """norm None: x is already normalised (the module-level `forward`)."""
         B, N, _d = x.shape
-        nw, nb = norm.norm_params()
+        nw, nb = norm.norm_params() if norm is not None else (None, None)
+        mode, eps = (norm.mode, norm.eps) if norm is not None else ('none', 0.0)
         bn = self.batch_norm
         y = Fn.conv_block(x.reshape(B * N, -1), nw, nb, self.pointwise_conv1.weight, self.pointwise_conv1.bias,
                           self.depthwise_conv.weight, self.depthwise_conv.bias, bn.weight, bn.bias, bn.running_mean,
                           bn.running_std, bn.num_batches_tracked, self.pointwise_conv2.weight, self.pointwise_conv2.bias,
-                          lengths, B, N, self.training, norm.mode, norm.eps, residual)
+                          lengths, B, N, self.training, mode, eps, residual)
         return y.view(B, N, -1)

@@ -9,6 +9,10 @@ class ASRLinearSCDecoder(nn.Module):
     def __init__(self, d_model, vocab_size, norm=False, norm_fn=RMSNorm, **kwargs):
         super().__init__()
         self.num_classes = vocab_size + 1                      # + blank
+        if self.num_classes % 16 != 0:
+            # the NT GEMM writes 16 output columns per lane and the softmax / CTC kernels move 4 classes per access
+            raise ValueError(f'vocab_size + 1 (blank) must be a multiple of 16 on the HIP path, got {self.num_classes}: use e.g. '
+                             f'vocab_size={(self.num_classes + 15) // 16 * 16 - 1} (the paper configs use 4095) and leave the extra ids unused')
         self.ff = nn.Linear(d_model, self.num_classes)
         self.reprojection = nn.Linear(self.num_classes, d_model)
         self.norm = norm_fn(d_model) if norm else nn.Identity()

@@ -24,8 +24,16 @@ class FusedMLP(nn.Module):
         self.fc2 = nn.Linear(hidden_features, out_features, bias=bias2, device=device, dtype=dtype)
 
     def forward_prenorm(self, x, norm, residual, scale=1.0):
+        """norm None: x is already normalised (the module-level `forward`)."""
         shape = x.shape
-        nw, nb = norm.norm_params()
+        nw, nb = norm.norm_params() if norm is not None else (None, None)
+        mode, eps = (norm.mode, norm.eps) if norm is not None else ('none', 0.0)
         y = Fn.ff_block(x.reshape(-1, shape[-1]), nw, nb, self.fc1.weight, self.fc2.weight, self.fc1.bias, self.fc2.bias,
-                        scale, norm.mode, norm.eps, self.checkpoint_lvl, residual)
-        return y.view(shape)
+                        scale, mode, eps, self.checkpoint_lvl, residual)
+        return y.view(*shape[:-1], y.shape[-1])
+
+    def forward(self, x, process_group=None):
+        """fc2(gelu_tanh(fc1(x))) — the reference's module-level call (fused_dense.py:489-498)."""
+        if process_group is not None:
+            raise NotImplementedError('tensor-parallel FusedMLP is dead code in the reference (SURVEY §2) and not implemented')
+        return self.forward_prenorm(x, None, False)

@@ -1,7 +1,8 @@
 """PreNorm / Scale (lcasr/components/wrappers.py:5-28): same module tree and state_dict keys.
 
 Module-level calls (``layer.ff1(x)``, ``layer.attend(x, ...)``, ``layer.conv(x, ...)``) return the residual
-BRANCH, like the reference; ConformerLayer.forward uses the fused branch+residual blocks instead."""
+BRANCH, like the reference.  ConformerLayer.forward passes ``residual=True``: the same modules then return
+``x + branch`` from the fused branch+residual block (forward hooks on them still fire)."""
 import torch.nn as nn
 
 from .normalisation import RMSNorm
@@ -16,9 +17,9 @@ class PreNorm(nn.Module):
         self.fn = fn
         self.sandwich_norm = sandwich_norm
 
-    def forward(self, x, **kwargs):
-        # the wrapped module fuses this PreNorm's norm into its first kernel
-        return self.fn.forward_prenorm(x, self.norm, residual=False, **kwargs)
+    def forward(self, x, residual=False, **kwargs):
+        # the wrapped module fuses this PreNorm's norm into its first kernel (and, with residual=True, `x +` into its last)
+        return self.fn.forward_prenorm(x, self.norm, residual=residual, **kwargs)
 
 
 class Scale(nn.Module):

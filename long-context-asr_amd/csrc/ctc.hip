@@ -32,8 +32,9 @@ __global__ void ctc_gather_kernel(const float* __restrict__ lp, const int* __res
         const long bt = idx / Lmax;
         const int t = (int)(bt % N), b = (int)(bt / N);
         float v = 0.f;
-        if (t < in_len[b] && s < 2 * tg_len[b] + 1) {
-            const int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
+        if (t < in_len[b] && s < 2 * tg_len[b] + 1 && s < Lmax) {
+            int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
+            lab = min(max(lab, 0), C - 1);               // an out-of-range label poisons the sample (alpha/beta kernel); never index with it
             v = lp[bt * C + lab];
         }
         lpg[idx] = v;
@@ -45,7 +46,7 @@ template <int MAXS>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ targets,
                                                              const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                              float* __restrict__ alpha, float* __restrict__ beta,
-                                                             float* __restrict__ nll, int B, int N, int Smax, int Lmax, int blank) {
+                                                             float* __restrict__ nll, int B, int N, int C, int Smax, int Lmax, int blank) {
     extern __shared__ float lat[];                      // [2][Lmax + 2], two leading -inf guard cells per row
     const int b = blockIdx.x % B;
     const bool is_beta = blockIdx.x >= B;
@@ -55,6 +56,14 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     const int nt = blockDim.x, tid = threadIdx.x;
     const int W = Lmax + 2;
     if (T <= 0) { if (!is_beta && tid == 0) nll[b] = INFINITY; return; }
+    // Inputs torch.nn.CTCLoss rejects on the host (input_length > N, target_length > Smax, a label outside [0, C)): the lengths
+    // live on the device here, so the sample is poisoned instead - nll = NaN, its gradient rows NaN (ctc_grad_kernel), which the
+    // optimiser's non-finite check turns into a skipped step - and nothing is indexed with the bad value.
+    {
+        int bad = (T > N) | (S < 0) | (S > Smax);
+        if (!bad) for (int i = tid; i < S; i += nt) { const int lab = targets[(long)b * Smax + i]; bad |= (lab < 0) | (lab >= C); }
+        if (__syncthreads_or(bad)) { if (!is_beta && tid == 0) nll[b] = NAN; return; }
+    }
 
     // per-state constants in MIRRORED coordinates sp (beta walks the reversed lattice)
     bool skip_ok[MAXS];
@@ -136,10 +145,17 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
         for (int c = threadIdx.x * 4; c < C; c += 1024) { float z[4] = {0.f, 0.f, 0.f, 0.f}; store4(gr + c, z); }
         return;
     }
+    const float nl = nll[b];
+    if (!(nl < INFINITY)) {
+        // No alignment fits (nll = +inf, zero_infinity=False): torch's backward evaluates exp(-inf + inf - lp) for every class
+        // of the sample's frames, i.e. the whole row is NaN - keep that signal instead of a half-valid gradient.  Also the
+        // poisoned samples (nll = NaN: invalid lengths / labels), whose lattice must not be walked.
+        for (int c = threadIdx.x * 4; c < C; c += 1024) { float z[4] = {NAN, NAN, NAN, NAN}; store4(gr + c, z); }
+        return;
+    }
     for (int c = threadIdx.x; c < C; c += 256) occ[c] = 0.f;
     __syncthreads();
     const int L = 2 * tg_len[b] + 1;
-    const float nl = nll[b];
     const long base = bt * Lmax;
     for (int s = threadIdx.x; s < L; s += 256) {
         const int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
@@ -147,12 +163,6 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
     __syncthreads();
     const float g = grad_out ? grad_out[b] : 1.f;          // per-sample upstream gradient
-    if (!(nl < INFINITY)) {
-        // No alignment fits (nll = +inf, zero_infinity=False): torch's backward evaluates exp(-inf + inf - lp) for every class
-        // of the sample's frames, i.e. the whole row is NaN - keep that signal instead of a half-valid gradient.
-        for (int c = threadIdx.x * 4; c < C; c += 1024) { float z[4] = {NAN, NAN, NAN, NAN}; store4(gr + c, z); }
-        return;
-    }
     for (int c = threadIdx.x * 4; c < C; c += 1024) {
         float v[4]; load4(lp + bt * C + c, v);
 #pragma unroll
@@ -183,7 +193,7 @@ SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, cons
 #define L(MS) do { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((ctc_alphabeta_kernel<MS>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
-                           target_lengths, alpha, beta, nll, (int)B, (int)N, (int)Smax, Lmax, blank); } while (0)
+                           target_lengths, alpha, beta, nll, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
     if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
 #undef L
     SCONF_LAUNCH_OK("sconf_ctc_fwd");

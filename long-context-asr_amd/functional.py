@@ -26,19 +26,32 @@ BF16, F32 = torch.bfloat16, torch.float32
 # ---- bf16 weight shadows ---------------------------------------------------------------------------------------------
 # The GEMMs read bf16 copies of the f32 master weights: a row-major copy (forward, NT) and a transposed copy (dgrad as
 # an NT GEMM).  The copies live in persistent buffers; `refresh_weight_shadows()` (called at the start of every model
-# forward, i.e. after any optimiser step / state-dict load / manual edit) re-derives ALL of them from the masters in one
-# kernel launch, so they can never be older than the forward that uses them.
+# forward) re-derives ALL of them from the masters in one kernel launch.  Module-level calls (layer.ff1(x), decoder(x), ...)
+# do not pass through the model forward, so every shadow also remembers the state of its master when it was cast - the
+# tensor's version counter plus an epoch that the fused optimiser bumps (its kernel writes the parameters behind autograd's
+# back) - and `wcast` / `wcast_t` re-cast a shadow whose master has moved on: a shadow can never be older than its use.
 class _Shadow:
-    __slots__ = ('w', 'rows', 'cols', 'n', 't')
+    __slots__ = ('w', 'rows', 'cols', 'n', 't', 'vn', 'vt')
 
     def __init__(self, w):
         self.w = w                                   # keeps the master alive and lets refresh re-read its data_ptr
         self.rows = w.shape[0]; self.cols = w.numel() // max(w.shape[0], 1)
         self.n = None; self.t = None
+        self.vn = self.vt = None                     # (version, epoch) of the master at the last cast of n / t
 
 
 _shadows: dict = {}                                  # (data_ptr, shape) -> _Shadow
 _table = {'key': None, 'dev': None, 'tiles': 0}
+_epoch = [0]
+
+
+def bump_weight_epoch() -> None:
+    """Parameters were rewritten in place by something autograd's version counters do not see (the fused MADGRAD kernel)."""
+    _epoch[0] += 1
+
+
+def _state(e: _Shadow):
+    return (e.w._version, _epoch[0])
 
 
 def clear_weight_cache() -> None:
@@ -62,6 +75,10 @@ def refresh_weight_shadows() -> None:
         rows.append([0, 0, 0, 0, 0, tile0])
         _table.update(key=key, dev=torch.tensor(rows, dtype=torch.int64, device=ents[0].w.device), tiles=tile0)
     ops.cast_shadows(_table['dev'], len(ents), _table['tiles'])
+    for e in ents:
+        st = _state(e)
+        if e.n is not None: e.vn = st
+        if e.t is not None: e.vt = st
 
 
 def _shadow(w: torch.Tensor) -> _Shadow:
@@ -78,8 +95,12 @@ def _shadow(w: torch.Tensor) -> _Shadow:
 def wcast(w: torch.Tensor) -> torch.Tensor:
     """bf16 copy of an f32 master weight, viewed 2-D (out_features, in_features*k)."""
     e = _shadow(w)
+    st = _state(e)
     if e.n is None:                                  # first use: cast now, refreshed in bulk from the next forward on
         e.n = ops.cast(w.detach().reshape(e.rows, e.cols), BF16)
+    elif e.vn != st:                                 # the master changed since the last cast (module-level use after an update)
+        e.n.copy_(ops.cast(w.detach().reshape(e.rows, e.cols), BF16))
+    e.vn = st
     return e.n
 
 
@@ -87,8 +108,12 @@ def wcast_t(w: torch.Tensor) -> torch.Tensor:
     """Transposed bf16 copy (in_features*k, out_features) of an f32 master weight: dgrad dx = dy W becomes the NT GEMM
     dy (W^T)^T whose B operand is K-contiguous (wide epilogue, no transposed LDS reads).  Weights are a few MB."""
     e = _shadow(w)
+    st = _state(e)
     if e.t is None:
         e.t = ops.cast_transpose(w.detach().reshape(e.rows, e.cols).contiguous())
+    elif e.vt != st:
+        e.t.copy_(ops.cast_transpose(w.detach().reshape(e.rows, e.cols).contiguous()))
+    e.vt = st
     return e.t
 
 
@@ -158,8 +183,20 @@ def _take_twin(dy: torch.Tensor):
     return ops.cast(dy, BF16), None
 
 
+def _pre(x, nw, nb, mode, eps):
+    """The PreNorm in front of a block -> (h bf16, mean, rstd).  mode 'none': the module-level forward() of the wrapped module
+    (attention.py:509, fused_dense.py:489, convolution.py:103), whose input is already normalised: a bf16 cast."""
+    if mode == 'none':
+        return ops.cast(x, BF16), None, None
+    return ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+
+
 def _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dres, dnw, dnb):
     """norm backward of a residual branch: dx = dres + norm'(x) dh (f32), with the bf16 twin parked for the receiving block."""
+    if mode == 'none':
+        if dres is not None:
+            raise RuntimeError('a block without its PreNorm has no fused residual')
+        return ops.cast(dh, x.dtype)
     if dres is None:
         return ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, None, F32, dnw, dnb)
     dx, dx16, cs = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dres, F32, dnw, dnb, twin=True)
@@ -226,7 +263,7 @@ class FFBlockFn(Function):
     @staticmethod
     def forward(ctx, x, nw, nb, w1, w2, b1, b2, scale: float, mode: str, eps: float, ckpt: int, residual: bool):
         x = x.contiguous()
-        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        h, mean, rstd = _pre(x, nw, nb, mode, eps)
         w1h, w2h = wcast(w1), wcast(w2)
         a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu_dsave', save_pre=True)   # u := gelu'(pre-activation), bf16
         y = ops.gemm(a, w2h, 'nt', bias=b2, resid=x if residual else None, alpha=scale, out_dtype=F32)
@@ -246,7 +283,7 @@ class FFBlockFn(Function):
         t = ctx.saved_tensors
         x, nw, nb, mean, rstd, w1h, w2h, b1, b2, w1t, w2t = t[:11]
         if ckpt >= 1:
-            h, _, _ = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+            h, _, _ = _pre(x, nw, nb, mode, eps)
             a, u = ops.gemm(h, w1h, 'nt', bias=b1, act='gelu_dsave', save_pre=True)
         else:
             h, u, a = t[11:]
@@ -276,8 +313,9 @@ class AttnBlockFn(Function):
     def forward(ctx, x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B: int, N: int, H: int, D: int, window,
                 mode: str, eps: float, residual: bool):
         x = x.contiguous()
-        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        h, mean, rstd = _pre(x, nw, nb, mode, eps)
         if lengths is not None:
+            if h is x: h = h.clone()
             ops.mask_rows_(h, lengths, B, N)                                          # attention.py:511
         wqh, woh = wcast(wqkv), wcast(wout)
         qkv = ops.gemm(h, wqh, 'nt', bias=bqkv)                                       # (M, H*D*3), "(h d qkv)" columns
@@ -329,7 +367,7 @@ class ConvBlockFn(Function):
                 B: int, N: int, training: bool, mode: str, eps: float, residual: bool):
         x = x.contiguous()
         d = x.shape[-1]
-        h, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
+        h, mean, rstd = _pre(x, nw, nb, mode, eps)
         w1h, w2h = wcast(wpw1), wcast(wpw2)
         g = ops.gemm(h, w1h, 'nt', bias=bpw1)                                         # (M, 2d)
         wdw2 = wdw.detach().reshape(d, -1).contiguous()
@@ -539,8 +577,18 @@ class CTCFn(Function):
 
 
 def ctc_nll(log_probs_bnc, targets, input_lengths, target_lengths, blank: int) -> torch.Tensor:
-    """Per-sample negative log-likelihoods (B,) from batch-major (B,N,C) f32 log-probs."""
+    """Per-sample negative log-likelihoods (B,) from batch-major (B,N,C) f32 log-probs.
+    Arguments torch.nn.CTCLoss rejects (input_length > N, target_length > targets.shape[1], a label outside [0, C)) raise
+    here when the tensors are on the host (checking costs nothing); for device tensors a check would stall the launch queue
+    for a whole forward, so the kernels poison the sample instead (nll and its gradient rows NaN - the optimiser skips the step)."""
     dev = log_probs_bnc.device
+    _B, _N, _C = log_probs_bnc.shape
+    if not input_lengths.is_cuda and input_lengths.numel() and int(input_lengths.max()) > _N:
+        raise ValueError(f'CTC: input_lengths must not exceed the {_N} time steps of log_probs')
+    if not target_lengths.is_cuda and target_lengths.numel() and (int(target_lengths.max()) > targets.shape[1] or int(target_lengths.min()) < 0):
+        raise ValueError('CTC: target_lengths out of range for the targets tensor')
+    if not targets.is_cuda and targets.numel() and (int(targets.min()) < 0 or int(targets.max()) >= _C):
+        raise ValueError(f'CTC: target labels must be in [0, {_C})')
     tg = targets.to(device=dev, dtype=torch.int32).contiguous()
     il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()

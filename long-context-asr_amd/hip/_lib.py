@@ -47,7 +47,8 @@ PROTOTYPES = {
     'sconf_overlap_finalize': [vp, vp, vp, i64, i64, vp],
     'sconf_argmax_rows': [vp, i64, i64, vp, vp],
     'sconf_sumsq': [vp, i64, vp, vp],
-    'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp],
+    'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp, vp],
+    'sconf_madgrad_advance': [vp, vp, f32, vp],
 }
 PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 

@@ -457,10 +457,21 @@ def sumsq_(g: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
 
 
 def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow: Optional[torch.Tensor], sumsq: Optional[torch.Tensor], max_norm: float,
-                  grad_scale: float, lr: float, momentum: float, eps: float, weight_decay: float, k: int) -> None:
+                  grad_scale: float, lr: float, momentum: float, eps: float, weight_decay: float, k) -> None:
+    """k: the steps applied so far, a Python int or a device int64 tensor (read by the kernel, no host sync).  At k == 0 the
+    kernel sets x0 := p."""
     for t, n in ((p, 'p'), (g, 'g'), (grad_sum_sq, 'grad_sum_sq'), (s, 's'), (x0, 'x0')): _chk(t, n, torch.float32)
+    k_dev = k if torch.is_tensor(k) else None
+    if k_dev is not None: _chk(k_dev, 'k', torch.int64)
     _lib.call('sconf_madgrad_step', _p(p), _p(g), _p(grad_sum_sq), _p(s), _p(x0), _p(shadow), p.numel(), _p(sumsq), float(max_norm),
-              float(grad_scale), float(lr), float(momentum), float(eps), float(weight_decay), int(k), _stream())
+              float(grad_scale), float(lr), float(momentum), float(eps), float(weight_decay), 0 if k_dev is not None else int(k),
+              _p(k_dev), _stream())
+
+
+def madgrad_advance_(k: torch.Tensor, sumsq: Optional[torch.Tensor], grad_scale: float = 1.0) -> None:
+    """k (device int64 scalar) += 1 unless the step was skipped because the gradient norm was not finite."""
+    _chk(k, 'k', torch.int64)
+    _lib.call('sconf_madgrad_advance', _p(k), _p(sumsq), float(grad_scale), _stream())
 
 
 # ------------------------------------------------------------------------------------------------

@@ -145,8 +145,8 @@ class ConformerLayer(nn.Module):
     def forward(self, x, lengths=None, rotary=None):
         """sconformer_xl.py:346-372 with every branch fused with its residual add.
         x (B,N,d) f32; lengths int32 (B,) on device when the batch is ragged, else None; rotary = (cos, sin) tables."""
-        x = self.ff1.fn.fn.forward_prenorm(x, self.ff1.fn.norm, residual=True, scale=self.ff1.scale)
-        x = self.attend.fn.forward_prenorm(x, self.attend.norm, residual=True, lengths=lengths, rotary=rotary)
-        x = self.conv.fn.forward_prenorm(x, self.conv.norm, residual=True, lengths=lengths)
-        x = self.ff2.fn.fn.forward_prenorm(x, self.ff2.fn.norm, residual=True, scale=self.ff2.scale)
+        x = self.ff1(x, residual=True)
+        x = self.attend(x, residual=True, lengths=lengths, rotary=rotary)
+        x = self.conv(x, residual=True, lengths=lengths)
+        x = self.ff2(x, residual=True)
         return self.norm_out(x)

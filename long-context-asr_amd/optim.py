@@ -20,8 +20,10 @@ class FlatParams:
     """Flatten a list of parameters into one f32 buffer (+ a gradient buffer of the same shape)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter]):
-        self.params: List[torch.nn.Parameter] = [p for p in params]
-        assert self.params, 'no parameters'
+        # frozen parameters (requires_grad=False) stay where they are: the reference optimiser skips parameters without a
+        # gradient (madgrad.py:113-114), so they must neither be decayed nor moved by the fused step
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        assert self.params, 'no trainable parameters'
         dev = self.params[0].device
         assert all(p.dtype == torch.float32 and p.device == dev for p in self.params), 'f32 parameters on one device expected'
         self.offsets, n = [], 0
@@ -73,10 +75,21 @@ class MADGRAD(torch.optim.Optimizer):
             self.flat.append(fp)
             group['_gss'] = torch.zeros_like(fp.data)
             group['_s'] = torch.zeros_like(fp.data)
-            group['_x0'] = fp.data.clone()
-        self.k = 0
-        self._sumsq = torch.zeros((), dtype=torch.float64, device=self.flat[0].data.device)
+            group['_x0'] = torch.zeros_like(fp.data)            # created by the kernel at the first applied step (k == 0: x0 := p),
+                                                                 # like the reference's lazy state (madgrad.py:121-125)
+        dev = self.flat[0].data.device
+        self._k = torch.zeros((), dtype=torch.int64, device=dev)   # steps APPLIED so far, on the device (skipped steps do not count)
+        self._sumsq = torch.zeros((), dtype=torch.float64, device=dev)
         self.last_sumsq: Optional[torch.Tensor] = None
+
+    @property
+    def k(self) -> int:
+        """Steps applied so far (host value; syncs)."""
+        return int(self._k)
+
+    @k.setter
+    def k(self, v: int) -> None:
+        self._k.fill_(int(v))
 
     def zero_grad(self, set_to_none: bool = False):
         for fp in self.flat:
@@ -91,9 +104,11 @@ class MADGRAD(torch.optim.Optimizer):
             ops.sumsq_(fp.grad, self._sumsq)
         for group, fp in zip(self.param_groups, self.flat):
             ops.madgrad_step_(fp.data, fp.grad, group['_gss'], group['_s'], group['_x0'], None, self._sumsq, max_norm,
-                              grad_scale, group['lr'], group['momentum'], group['eps'], group['weight_decay'], self.k)
-        self.k += 1
+                              grad_scale, group['lr'], group['momentum'], group['eps'], group['weight_decay'], self._k)
+        ops.madgrad_advance_(self._k, self._sumsq, grad_scale)
         self.last_sumsq = self._sumsq
+        from . import functional as _Fn
+        _Fn.bump_weight_epoch()                                # the kernel wrote the parameters without bumping their version counters
         return loss
 
     # ---- checkpoint compatibility with lcasr.optim.madgrad.MADGRAD (optim/madgrad.py:95-130) --------------------------
@@ -104,19 +119,22 @@ class MADGRAD(torch.optim.Optimizer):
 
     def state_dict(self):
         state, groups, idx = {}, [], 0
+        k = self.k
         for group, fp in zip(self.param_groups, self.flat):
             ids = []
-            for p, o in zip(fp.params, fp.offsets):
-                n = p.numel()
-                if self.k > 0:
+            where = {id(p): o for p, o in zip(fp.params, fp.offsets)}
+            for p in group['params']:                            # indices count every parameter of the group, like torch's
+                o = where.get(id(p))
+                if k > 0 and o is not None:                      # frozen parameters have no state (madgrad.py:113-114)
+                    n = p.numel()
                     state[idx] = {name: group[key][o:o + n].view(p.shape).clone()
                                   for name, key in (('grad_sum_sq', '_gss'), ('s', '_s'), ('x0', '_x0'))}
                 ids.append(idx); idx += 1
-            g = {k: v for k, v in group.items() if k not in self._PRIVATE}
+            g = {k_: v for k_, v in group.items() if k_ not in self._PRIVATE}
             g['params'] = ids
             groups.append(g)
-        if self.k > 0:
-            state['k'] = torch.tensor([self.k], dtype=torch.long)
+        if k > 0:
+            state['k'] = torch.tensor([k], dtype=torch.long)
         return {'state': state, 'param_groups': groups}
 
     @torch.no_grad()
@@ -126,20 +144,24 @@ class MADGRAD(torch.optim.Optimizer):
             raise ValueError('loaded state dict has a different number of parameter groups')
         idx = 0
         for saved, group, fp in zip(groups, self.param_groups, self.flat):
-            if len(saved['params']) != len(fp.params):
+            if len(saved['params']) != len(group['params']):
                 raise ValueError("loaded state dict contains a parameter group that doesn't match the size of optimizer's group")
             for k, v in saved.items():
                 if k not in self._PRIVATE:
                     group[k] = v
-            for p, o in zip(fp.params, fp.offsets):
+            where = {id(p): o for p, o in zip(fp.params, fp.offsets)}
+            for p in group['params']:
                 st = state.get(idx, state.get(str(idx)))
+                o = where.get(id(p))
+                idx += 1
+                if o is None:
+                    continue
                 n = p.numel()
                 if st is not None:
                     for name, key in (('grad_sum_sq', '_gss'), ('s', '_s'), ('x0', '_x0')):
                         group[key][o:o + n].copy_(st[name].reshape(-1).to(group[key]))
                 else:                                            # the reference would create it at the next step
                     group['_gss'][o:o + n].zero_(); group['_s'][o:o + n].zero_(); group['_x0'][o:o + n].copy_(fp.data[o:o + n])
-                idx += 1
         k = state.get('k', None)
         self.k = int(k.reshape(-1)[0]) if k is not None else 0
 

@@ -43,10 +43,21 @@ class GradSync:
                 self.buckets.append((start, flat_grad.numel() if last else ends[i], count))
                 start, count = ends[i], 0
         self.pending = [0] * len(self.buckets)
+        self.next_bucket = len(self.buckets) - 1            # buckets are issued in DESCENDING index order, always
         self.handles = []
         self._hooks = []
         self._index = {id(p): i for i, p in enumerate(params)}
-        self._seen, self._expect = {}, None                 # direct-write counts of this backward / of the first one
+        # When is a parameter's gradient final?  Two sources announce "one more contribution to parameter i has landed":
+        #   'd'  functional's direct-write mode (the backward kernels accumulate straight into the flat buffer and call
+        #        on_grad_ready), and
+        #   'a'  autograd's post-accumulate hooks (gradients returned to autograd).  torch fires these hooks once per USE of the
+        #        parameter - even when a backward returned None for it - so under direct writes BOTH sources speak for the
+        #        same parameter: counting both released buckets half-way through the backward (found by the world-size-2 test
+        #        of the real model in round 2).
+        # A parameter used by several blocks (the decoder inside every self-conditioning layer) is announced several times per
+        # backward.  The first backward only counts, per source; from then on a parameter listens to ONE source - the direct
+        # one if it ever spoke for it - and is released on that source's last announcement.
+        self._seen, self._expect = {'d': {}, 'a': {}}, None
         if self.world > 1:
             for i, p in enumerate(params):
                 if p.requires_grad:
@@ -55,45 +66,60 @@ class GradSync:
 
     def on_grad_ready(self, p: torch.nn.Parameter) -> None:
         """A backward kernel has accumulated this parameter's gradient straight into the flat buffer
-        (functional.set_direct_grad): autograd's post-accumulate hook will not fire for it, so count it here."""
+        (functional.set_direct_grad)."""
         i = self._index.get(id(p))
-        if i is None or self.world == 1:
-            return
-        # A parameter used by several blocks (the decoder inside every self-conditioning layer) is written several times
-        # per backward.  The first backward only counts the writes; later ones release the parameter on its last write.
-        self._seen[i] = self._seen.get(i, 0) + 1
-        if self._expect is not None and self._seen[i] == self._expect.get(i, 0):
-            self._ready(i)
+        if i is not None and self.world > 1:
+            self._event(i, 'd')
+
+    def _event(self, i, src):
+        seen = self._seen[src]
+        seen[i] = seen.get(i, 0) + 1
+        if self._expect is not None:
+            e = self._expect.get(i)
+            if e is not None and e[0] == src and seen[i] == e[1]:
+                self._ready(i)
 
     def reset(self):
         self.pending = [n for (_, _, n) in self.buckets]
+        self.next_bucket = len(self.buckets) - 1
         self.handles = []
-        self._seen = {}
+        self._seen = {'d': {}, 'a': {}}
+
+    def _issue(self, b):
+        s, e, _ = self.buckets[b]
+        self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _ready(self, i):
+        # Collectives are matched across ranks by issue order, so the order must not depend on the order in which THIS rank's
+        # backward happened to finish its parameters (nor on whether it ran a backward at all: a rank with nothing to train in
+        # a step still takes part, see finish()).  Buckets therefore go out in descending index order - the order the backward
+        # completes them in anyway (parameters are registered in forward order) - each as soon as it and all later ones are final.
         b = self.param_bucket[i]
         self.pending[b] -= 1
-        if self.pending[b] == 0:
-            s, e, _ = self.buckets[b]
-            self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        while self.next_bucket >= 0 and self.pending[self.next_bucket] <= 0:
+            self._issue(self.next_bucket)
+            self.next_bucket -= 1
 
     def _make_hook(self, i):
         def hook(_p):
-            self._ready(i)
+            self._event(i, 'a')
         return hook
 
     def finish(self):
         """Wait for the in-flight all-reduces; reduce any bucket whose hooks did not all fire (unused parameters)."""
         if self.world > 1:
-            if self._expect is None:
-                self._expect = dict(self._seen)
-            elif any(n > self._expect.get(i, 0) for i, n in self._seen.items()):
-                raise RuntimeError('GradSync: a parameter received more direct gradient writes than in the first backward; '
+            if not self._seen['d'] and not self._seen['a']:
+                pass                                            # this rank ran no backward in this step
+            elif self._expect is None:
+                self._expect = {i: ('a', n) for i, n in self._seen['a'].items()}
+                self._expect.update({i: ('d', n) for i, n in self._seen['d'].items()})
+            elif any(self._expect.get(i, (src, 0))[0] == src and n > self._expect.get(i, (src, 0))[1]
+                     for src in ('d', 'a') for i, n in self._seen[src].items()):
+                raise RuntimeError('GradSync: a parameter received more gradient contributions than in the first backward; '
                                    'its bucket may have been reduced early (the graph must not change between steps)')
-            for b, n in enumerate(self.pending):
-                if n > 0:
-                    s, e, _ = self.buckets[b]
-                    self.handles.append(dist.all_reduce(self.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            while self.next_bucket >= 0:                      # whatever the hooks did not release (unused parameters; a rank that
+                self._issue(self.next_bucket)                  # ran no backward in this step contributes its zero gradients)
+                self.next_bucket -= 1
             for h in self.handles:
                 h.wait()
         self.reset()

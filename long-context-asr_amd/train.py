@@ -62,6 +62,15 @@ class Trainer:
         self.opt.zero_grad()
         return loss.detach()
 
+    def step_without_data(self):
+        """This rank has nothing to train in a step the other ranks do take (its recordings have run out): contribute zero
+        gradients to the same all-reduces and apply the same optimiser step, so that every rank issues the same collectives and
+        the replicas stay identical."""
+        self.sync.finish()
+        self.opt.step(max_norm=self.clip_value)
+        self.opt.zero_grad()
+        return None
+
     def train_recording(self, audio, audio_lengths, chunk_size: int, chunk_overlap: int, targets_for_chunk):
         """One batch of long recordings, chunk by chunk (exp/train.py:174-293 with backwards_every = backprop_every = 1, the
         paper configs): audio (B, F, T_total), audio_lengths (B,) frames.  Recordings that have run out drop out of the batch
@@ -69,18 +78,40 @@ class Trainer:
         targets_for_chunk(ix, chunk) -> (targets (B', S), target_lengths (B',)) for the rows alive in chunk ix (the text side
         of the reference's chunker is data plumbing; the benchmark feeds synthetic targets).  Returns the per-chunk losses."""
         from .utils.dataloading import chunk_spectogram, plan_chunks
+        import torch.distributed as dist
         plan = plan_chunks(chunk_spectogram(audio, chunk_size, chunk_overlap), audio_lengths, chunk_overlap)
-        nominal = audio.shape[0] * self.sync.world
+        world = self.sync.world
+        nominal = audio.shape[0] * world
+        n_chunks = len(plan)
+        if world > 1:
+            # The reference has no data parallelism; here every optimiser step is a set of collectives, so all ranks must take
+            # the same number of steps although their recordings differ in length: agree on the longest plan, and per chunk on
+            # whether ANY rank has something to train (a rank that has not runs `step_without_data`).
+            t = torch.tensor([n_chunks], dtype=torch.int64, device=audio.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.sync.group)
+            n_chunks = int(t)
         losses = []
-        for ix, c in enumerate(plan):
-            keep = c['audio_lengths'] > 0                       # an exactly exhausted recording: the reference feeds a zero-length
-            if not bool(keep.all()):                            # row and lands in its NaN-skip branch; here the row is dropped
-                c = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in c.items()}
-            if c['audio'].shape[0] == 0:
+        for ix in range(n_chunks):
+            work = None
+            if ix < len(plan):
+                c = plan[ix]
+                keep = c['audio_lengths'] > 0                   # an exactly exhausted recording: the reference feeds a zero-length
+                if not bool(keep.all()):                        # row and lands in its NaN-skip branch; here the row is dropped
+                    c = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in c.items()}
+                if c['audio'].shape[0] > 0:
+                    tg, tl = targets_for_chunk(ix, c)
+                    if int(tl.max()) > 0:                       # train.py:186-187: nothing to align in this chunk -> skipped
+                        work = (c['audio'].contiguous(), c['audio_lengths'], tg, tl)
+            if world > 1:
+                t = torch.tensor([int(work is not None)], dtype=torch.int64, device=audio.device)
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.sync.group)
+                if int(t) == 0:
+                    continue                                    # no rank has work: everyone skips together
+                if work is None:
+                    self.step_without_data()
+                    continue
+            elif work is None:
                 continue
-            tg, tl = targets_for_chunk(ix, c)
-            if int(tl.max()) == 0:                              # train.py:186-187: nothing to align in this chunk
-                continue
-            losses.append(self.step(c['audio'].contiguous(), c['audio_lengths'], tg, tl, norm_frames=chunk_size, norm_batch=nominal))
+            losses.append(self.step(*work, norm_frames=chunk_size, norm_batch=nominal))
         return losses
 

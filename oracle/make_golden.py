@@ -48,6 +48,7 @@ TINY = dict(vocab_size=127, n_layers=2, d_model=64, n_heads=2, head_dim=32, subs
 C1 = dict(vocab_size=4095, n_layers=6, d_model=256, n_heads=8, head_dim=32, subsampling_conv_channels=256,
           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True, bias_in_ff=False,
           default_norm='layer_norm')
+C2 = dict(C1, d_model=768, n_heads=6, head_dim=128)           # BASELINE configs[1]: 6L/768D/6H, seq=1024
 
 
 def synth(B, T, V, lengths=None, seed=0):
@@ -67,11 +68,34 @@ def np_sd(sd):
     return {k: v.detach().cpu().numpy() for k, v in sd.items()}
 
 
-def run_case(SC, kw, B, T, lengths, tag, save_all_grads=True, save_weights=True, max_abs_tol=2e-5):
+GS_CAP = 8192          # 'gs.' entries: every gradient tensor, flattened and strided down to at most this many elements
+
+
+def strided(v, cap=GS_CAP):
+    flat = v.reshape(-1)
+    step = max(1, -(-flat.numel() // cap))
+    return flat[::step]
+
+
+def perturb_brn(model, nbt=30000):
+    """Move the BatchRenorm buffers off their init (running_mean 0, running_std 1, nbt 0 -> r = 1, d = 0 whatever the
+    statistics) so that the r / d clamps are live: rmax(30000) = 2.43, dmax = 5."""
+    g = torch.Generator().manual_seed(77)
+    with torch.no_grad():
+        for l in model.layers:
+            bn = l.conv.fn.batch_norm
+            bn.running_mean.copy_(0.05 * torch.randn(bn.running_mean.shape, generator=g))
+            bn.running_std.copy_(0.15 + 0.3 * torch.rand(bn.running_std.shape, generator=g))
+            bn.num_batches_tracked.fill_(nbt)
+
+
+def run_case(SC, kw, B, T, lengths, tag, save_all_grads=True, save_weights=True, max_abs_tol=2e-5, prep=None, strided_grads=False):
     from oracle import sconformer_ref as O
     torch.manual_seed(12345)                                   # exp/train.py:363
     model = SC(**kw)
     model.train()
+    if prep is not None:
+        prep(model)
     V = kw['vocab_size']
     x, ln, tg, tl = synth(B, T, V, lengths)
     sd0 = {k: v.clone() for k, v in model.state_dict().items()}
@@ -138,8 +162,35 @@ def run_case(SC, kw, B, T, lengths, tag, save_all_grads=True, save_weights=True,
         for k, v in ref_grads.items(): fx['g.' + k] = v.numpy()
     else:
         for k, v in ref_grads.items(): fx['gnorm.' + k] = np.float64(float(v.double().norm()))
+    if strided_grads:                                          # a strided sample of EVERY gradient tensor (relative-L2 parity)
+        for k, v in ref_grads.items(): fx['gs.' + k] = strided(v).numpy().copy()
+        fx['gs_cap'] = np.array(GS_CAP)
     np.savez_compressed(os.path.join(GOLD, tag + '.npz'), **fx)
     return model
+
+
+def chunk_case():
+    """f2: `chunk_spectogram` (lcasr/utils/dataloading.py:14-25) run on integer-valued spectrograms.  The module's top-level
+    imports need torchaudio (absent here), so the function's own definition is taken out of the file's syntax tree and
+    executed as is (it only touches torch); nothing of the file is written anywhere."""
+    import ast
+    src = open(REF + '/lcasr/utils/dataloading.py').read()
+    node = next(n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == 'chunk_spectogram')
+    ns = {'torch': torch}
+    exec(compile(ast.Module(body=[node], type_ignores=[]), REF + '/lcasr/utils/dataloading.py', 'exec'), ns)
+    ref_fn = ns['chunk_spectogram']
+    fx = {}
+    cases = [(1000, 256, 64), (1000, 256, 0), (1000, 400, 8), (513, 512, 1), (77, 128, 32), (2048, 2048, 0), (300, 100, 99)]
+    fx['cases'] = np.array(cases)
+    for ci, (T, size, ov) in enumerate(cases):
+        spec = torch.arange(2 * 3 * T, dtype=torch.float32).view(2, 3, T)
+        chunks = ref_fn(spec, size, ov)
+        fx[f'n.{ci}'] = np.array(len(chunks))
+        fx[f'widths.{ci}'] = np.array([c.shape[-1] for c in chunks])
+        fx[f'first.{ci}'] = np.array([float(c[0, 0, 0]) for c in chunks])          # = start frame of each chunk
+        fx[f'sum.{ci}'] = np.array([float(c.double().sum()) for c in chunks])
+    np.savez_compressed(os.path.join(GOLD, 'chunks.npz'), **fx)
+    print('[chunks] wrote', len(cases), 'cases')
 
 
 def attention_cases(attention_ref):
@@ -300,6 +351,15 @@ def main():
         SC, _, MADGRAD = load_reference()
         torch.set_num_threads(8)
         return infer_case(SC) if sys.argv[1] == 'infer' else schedule_and_checkpoint_case(MADGRAD)
+    if len(sys.argv) > 1 and sys.argv[1] == 'r2':                # the fixtures added in round 2 only
+        SC, _, _ = load_reference()
+        torch.set_num_threads(8)
+        run_case(SC, C1, 2, 1024, None, 'c1_scalars', save_all_grads=False, save_weights=False, max_abs_tol=2e-4, strided_grads=True)
+        run_case(SC, C2, 2, 1024, None, 'c2_scalars', save_all_grads=False, save_weights=False, max_abs_tol=5e-4, strided_grads=True)
+        run_case(SC, dict(TINY, default_norm='layer_norm', checkpoint_every_n_layers=1, ff_checkpoint_lvl=2), 2, 256, [256, 200],
+                 'tiny_ln_ckpt', prep=perturb_brn)
+        run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200], 'tiny_ln_brn', prep=perturb_brn)
+        return chunk_case()
     assert os.path.isdir(REF), 'reference not present: this script only runs in the development container'
     os.makedirs(GOLD, exist_ok=True)
     SC, attention_ref, MADGRAD = load_reference()
@@ -308,7 +368,13 @@ def main():
     run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, None, 'tiny_ln_equal')
     run_case(SC, dict(TINY, default_norm='rms_norm'), 2, 256, [256, 200], 'tiny_rms_ragged')
     run_case(SC, dict(TINY, default_norm='layer_norm'), 3, 1000, [1000, 1023 - 40, 17 * 8], 'tiny_ln_odd')
-    run_case(SC, C1, 2, 1024, None, 'c1_scalars', save_all_grads=False, save_weights=False, max_abs_tol=2e-4)
+    run_case(SC, C1, 2, 1024, None, 'c1_scalars', save_all_grads=False, save_weights=False, max_abs_tol=2e-4, strided_grads=True)
+    run_case(SC, C2, 2, 1024, None, 'c2_scalars', save_all_grads=False, save_weights=False, max_abs_tol=5e-4, strided_grads=True)
+    # BASELINE config 4's switches (exp_set_seq_rotary_base_9l.yaml:52-53) on the tiny model, BatchRenorm clamps live
+    run_case(SC, dict(TINY, default_norm='layer_norm', checkpoint_every_n_layers=1, ff_checkpoint_lvl=2), 2, 256, [256, 200],
+             'tiny_ln_ckpt', prep=perturb_brn)
+    run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200], 'tiny_ln_brn', prep=perturb_brn)
+    chunk_case()
     attention_cases(attention_ref)
     madgrad_case(MADGRAD)
     infer_case(SC)

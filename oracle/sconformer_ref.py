@@ -46,6 +46,7 @@ DEFAULTS = dict(
     conv_kernel_size=9, conv_expansion_factor=1, decoder_norm=False, use_rotary=False,
     rotary_interpolation_factor=1.0, self_conditioning=True, default_norm='layer_norm',
     bias_in_ff=False, legasee_double_norm=True, rotary_base_freq=10000,
+    checkpoint_every_n_layers=0, ff_checkpoint_lvl=0,
 )
 
 
@@ -236,6 +237,23 @@ def conformer_layer(x, sd, i, cfg, lengths, rot, training, new_buffers=None, cap
     return x
 
 
+def checkpointed_layer(x, sd, i, cfg, lengths, rot, new_buffers, window=(-1, -1)):
+    """torch.utils.checkpoint around a layer in TRAIN mode — sconformer_xl.py:221-230.  The layer runs twice: once in the
+    forward (no graph; its output is what the rest of the forward sees) and once more inside the backward (the recompute, whose
+    graph carries the gradient).  BatchRenorm is stateful, so the recompute (a) reads the running statistics the first run
+    already moved - its r / d clamps, which are constants of the graph, differ from the first run's - and (b) moves the
+    running statistics and num_batches_tracked a SECOND time (measured on the reference: nbt = 2 after one step).
+    ff_checkpoint_lvl (fused_dense.py:283-289) only changes what is kept for the backward, never a value."""
+    nb1: dict = {}
+    with torch.no_grad():
+        y1 = conformer_layer(x.detach(), sd, i, cfg, lengths, rot, True, nb1, None, window)
+    nb2: dict = {}
+    y2 = conformer_layer(x, {**sd, **nb1}, i, cfg, lengths, rot, True, nb2, None, window)
+    if new_buffers is not None:
+        new_buffers.update(nb2)
+    return y2 + (y1 - y2).detach()
+
+
 def decoder_logits(x, sd, cfg):
     """ASRLinearSCDecoder.forward(logits=True) — decoder.py:22-26."""
     if cfg['decoder_norm']:
@@ -266,8 +284,12 @@ def forward(sd: Dict[str, Tensor], cfg: dict, audio_bft: Tensor, lengths: Option
         rot = (cos[:N], sin[:N])
     mlen = None if int(length.max()) == int(length.min()) else length   # sconformer_xl.py:204-205
     nb = new_buffers
+    every = cfg.get('checkpoint_every_n_layers', 0)
     for i in range(cfg['n_layers']):
-        x = conformer_layer(x, sd, i, cfg, mlen, rot, training, nb, cap, window)
+        if every > 0 and i % every == 0 and training and torch.is_grad_enabled() and x.requires_grad:
+            x = checkpointed_layer(x, sd, i, cfg, mlen, rot, nb, window)
+        else:
+            x = conformer_layer(x, sd, i, cfg, mlen, rot, training, nb, cap, window)
         if i != cfg['n_layers'] - 1 and cfg['self_conditioning']:
             post = decoder_logits(x, sd, cfg).softmax(dim=-1)   # sconformer_xl.py:241-243
             x = x + F.linear(post, sd['decoder.reprojection.weight'], sd['decoder.reprojection.bias'])

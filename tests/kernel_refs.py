@@ -28,10 +28,11 @@ def _gelu(x): return F.gelu(x, approximate='tanh')
 
 
 def _dgelu(x):
-    x = x.detach().clone().requires_grad_(True)
-    with torch.enable_grad():
-        _gelu(x).sum().backward()
-    return x.grad
+    # closed form (no inner autograd: this runs inside Function.forward, possibly under torch.utils.checkpoint, whose saved-tensor
+    # hooks would see an inner backward as a reason to recompute the region)
+    k = math.sqrt(2.0 / math.pi)
+    t = torch.tanh(k * (x + 0.044715 * x ** 3))
+    return 0.5 * (1 + t) + 0.5 * x * (1 - t * t) * k * (1 + 3 * 0.044715 * x * x)
 
 
 def _dsilu(x):
@@ -396,7 +397,9 @@ def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow, sumsq, max_norm, grad_scale,
         if max_norm > 0: coef *= min(1.0, max_norm / (tot + 1e-6))
     if lr != 0: lr = lr + eps
     ck = 1 - momentum
+    k = int(k)
     lamb = lr * math.sqrt(k + 1)
+    if k == 0: x0.copy_(p)
     gv = g * coef
     if weight_decay != 0: gv = gv + weight_decay * p
     grad_sum_sq.addcmul_(gv, gv, value=lamb)
@@ -405,6 +408,11 @@ def madgrad_step_(p, g, grad_sum_sq, s, x0, shadow, sumsq, max_norm, grad_scale,
     z = x0.addcdiv(s, rms, value=-1)
     p.mul_(1 - ck).add_(z, alpha=ck)
     if shadow is not None: shadow.copy_(p)
+
+
+def madgrad_advance_(k, sumsq, grad_scale=1.0):
+    if sumsq is not None and not math.isfinite(math.sqrt(float(sumsq)) * abs(grad_scale)): return
+    k.add_(1)
 
 
 def overlap_add_exp_(logp, acc, count, pos0, stride):

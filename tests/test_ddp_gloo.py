@@ -136,3 +136,128 @@ def test_flat_params_views_and_zero_grad():
     assert float(fp.grad.abs().sum()) > 0
     fp.zero_grad()
     assert float(fp.grad.abs().sum()) == 0 and all(float(p.grad.abs().sum()) == 0 for p in m.parameters())
+
+
+# ---- the REAL training driver under world_size 2 (gloo, CPU, the HIP op layer swapped for tests/kernel_refs.py) ------------------
+def _emulate():
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import kernel_refs
+    import lcasr_amd.functional as Fn
+    import lcasr_amd.optim as OPT
+    Fn.ops = kernel_refs; OPT.ops = kernel_refs
+    Fn.clear_weight_cache()
+
+
+def _tiny_model():
+    from common_model import build_from_fixture
+    from conftest import load_golden
+    fx = load_golden('tiny_ln_ragged')
+    return build_from_fixture(fx, 'cpu'), int(fx['cfg.vocab_size'])
+
+
+def _global_batch(V):
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(4, 80, 256, generator=g)
+    ln = torch.tensor([256, 200, 256, 232])
+    tg = torch.randint(0, V, (4, 8), generator=g)
+    tl = torch.tensor([8, 6, 7, 8])
+    return x, ln, tg, tl
+
+
+def _trainer_worker(rank, world, port, out):
+    _emulate()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lcasr_amd.parallel import broadcast_module_state
+    from lcasr_amd.train import Trainer
+    m, V = _tiny_model()
+    broadcast_module_state(m)
+    tr = Trainer(m, lr=3e-3, clip_value=0.8, global_batch=4, bucket_bytes=32 << 10)      # several buckets: the decoder's is one
+    assert len(tr.sync.buckets) > 3
+    x, ln, tg, tl = _global_batch(V)
+    sl = slice(rank * 2, rank * 2 + 2)
+    losses = [float(tr.step(x[sl], ln[sl], tg[sl], tl[sl])) for _ in range(3)]           # step 1 learns the write counts
+    expect = dict(tr.sync._expect)
+    dec = [tr.sync._index[id(p)] for p in m.decoder.parameters()]
+    assert all(expect[i][0] == 'd' for i in expect), expect                               # every parameter is written directly
+    assert all(expect[i][1] >= 2 for i in dec[:2]), expect                                # decoder.ff: once per SC layer + the head
+    torch.save(dict(losses=losses, data=tr.opt.flat[0].data.clone(), nbt=int(m.layers[0].conv.fn.batch_norm.num_batches_tracked)),
+               out + f'.{rank}')
+    dist.destroy_process_group()
+
+
+def test_real_trainer_step_world2_matches_single_process_sum_of_shards(tmp_path, emulated_ops, monkeypatch):
+    """Trainer.step (direct gradient writes into the flat buffer, decoder written L times per backward, first-step counting,
+    descending-order bucket release) on 2 gloo ranks == one process that back-propagates the two shards one after the other
+    into the same gradient buffer (BatchRenorm statistics are per shard in both) and applies one clipped MADGRAD step."""
+    port = 33500 + (os.getpid() % 2000)
+    out = str(tmp_path / 'r')
+    mp.spawn(_trainer_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+    assert torch.equal(r0['data'], r1['data']), 'replicas diverged'
+    import kernel_refs
+    import lcasr_amd.functional as Fn
+    import lcasr_amd.optim as OPT
+    from lcasr_amd.losses import CTCLoss
+    from lcasr_amd.optim import MADGRAD
+    monkeypatch.setattr(OPT, 'ops', kernel_refs)                 # (the workers patched their own processes; this one is restored)
+    m, V = _tiny_model()
+    opt = MADGRAD(m.parameters(), lr=3e-3)
+    x, ln, tg, tl = _global_batch(V)
+    ctc = CTCLoss(blank=V, reduction='sum')
+    ref_losses = []
+    for _ in range(3):
+        step_losses = []
+        for sl in (slice(0, 2), slice(2, 4)):
+            o = m(x[sl], length=ln[sl])
+            loss = ctc(o['final_posteriors'].transpose(0, 1), tg[sl], o['length'], tl[sl])
+            (loss / (256 * 4) * 100).backward()
+            step_losses.append(float(loss))
+        opt.step(max_norm=0.8); opt.zero_grad()
+        ref_losses.append(step_losses)
+    Fn.clear_weight_cache()
+    assert [l[0] for l in ref_losses][0] == pytest.approx(r0['losses'][0], rel=1e-6)
+    assert [l[1] for l in ref_losses][0] == pytest.approx(r1['losses'][0], rel=1e-6)
+    # rank 0's BatchRenorm saw one shard per step; the single process above saw two per step
+    assert r0['nbt'] == 3
+    d = (r0['data'] - opt.flat[0].data).abs()
+    assert float(d.max()) < 5e-5, float(d.max())
+    for i in (1, 2):
+        assert ref_losses[i][0] == pytest.approx(r0['losses'][i], rel=2e-3) and ref_losses[i][1] == pytest.approx(r1['losses'][i], rel=2e-3)
+
+
+def _recording_worker(rank, world, port, out):
+    _emulate()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lcasr_amd.parallel import broadcast_module_state
+    from lcasr_amd.train import Trainer
+    m, V = _tiny_model()
+    broadcast_module_state(m)
+    tr = Trainer(m, lr=1e-3, global_batch=4, bucket_bytes=32 << 10)
+    g = torch.Generator().manual_seed(50 + rank)
+    lens = torch.tensor([1000, 530]) if rank == 0 else torch.tensor([256, 90])           # 6 chunks on rank 0, 2 on rank 1
+    audio = torch.randn(2, 80, int(lens.max()), generator=g)
+    for b, l in enumerate(lens.tolist()): audio[b, :, l:] = 0
+
+    def targets(ix, c):
+        tl_ = ((c['audio_lengths'] // 8) // 4).clamp(min=1)
+        return torch.randint(0, V, (c['audio'].shape[0], int(tl_.max())), generator=g), tl_
+
+    losses = tr.train_recording(audio, lens, 256, 64, targets)
+    torch.save(dict(n=len(losses), k=tr.opt.k, data=tr.opt.flat[0].data.clone(), finite=all(bool(torch.isfinite(l)) for l in losses)),
+               out + f'.{rank}')
+    dist.destroy_process_group()
+
+
+def test_train_recording_world2_unequal_recordings_stay_in_lockstep(tmp_path):
+    """ranks whose recordings differ in length must still issue the same collectives.  Rank 0 has 6 chunks, rank 1
+    has 2: rank 1 takes part in steps 3-6 with zero gradients (Trainer.step_without_data), both apply 6 optimiser steps and
+    end with identical parameters; nothing hangs."""
+    port = 35500 + (os.getpid() % 2000)
+    out = str(tmp_path / 'r')
+    mp.spawn(_recording_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+    assert (r0['n'], r1['n']) == (6, 2) and r0['finite'] and r1['finite']
+    assert r0['k'] == r1['k'] == 6
+    assert torch.equal(r0['data'], r1['data'])

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from common_model import TINY_CASES, build_from_fixture, grad_errors, run_step
+from common_model import TINY_CASES, build_from_fixture, grad_errors, rel_l2_errors, run_step
 from conftest import golden_cfg, golden_state_dict, load_golden
 
 
@@ -34,7 +34,7 @@ def test_product_path_refuses_cpu_without_fallback():
         m(torch.from_numpy(fx['x']))
 
 
-@pytest.mark.parametrize('case', TINY_CASES)
+@pytest.mark.parametrize('case', TINY_CASES + ['tiny_ln_brn', 'tiny_ln_ckpt'])
 def test_wiring_against_reference_fixture(emulated_ops, case):
     """bf16-storage emulation of the kernels, f32 math: must track the reference's fp32 CPU path to bf16 noise."""
     fx = load_golden(case)
@@ -45,10 +45,9 @@ def test_wiring_against_reference_fixture(emulated_ops, case):
     d = (r['logp'] - ref_lp).abs()
     assert float(d.max()) < 0.3 and float(d.mean()) < 0.03, (float(d.max()), float(d.mean()))
     assert abs(r['loss'] - float(fx['loss'])) / float(fx['loss']) < 2e-3
-    errs = grad_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')})
-    worst = max(errs.values())
-    assert worst < 0.3, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    for k in fx.files:
+    errs = rel_l2_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')})
+    assert max(errs.values()) < 0.12 and float(np.median(list(errs.values()))) < 0.05, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    for k in fx.files:                                          # tiny_ln_ckpt: moved TWICE (the recompute runs in train mode), nbt += 2
         if k.startswith('buf.'):
             got = m.state_dict()[k[4:]].float()
             assert float((got - torch.from_numpy(fx[k]).float()).abs().max()) < 2e-3, k
@@ -182,6 +181,14 @@ def test_chunk_plan_schedules_and_optimizer_state_layout():
     for i in range(30): opt.step(); sch.step(); lrs.append(sch.get_last_lr()[0])
     assert np.allclose(lrs, fx['cosine_lrs'], rtol=1e-12, atol=0)
     assert sorted(sch.state_dict().keys()) == fx['cosine_state_keys'].tolist()
+    # chunk_spectogram against the reference function's own output (chunks.npz, oracle/make_golden.py::chunk_case)
+    cx = load_golden('chunks')
+    for ci, (T, size, ov) in enumerate(cx['cases'].tolist()):
+        sp = torch.arange(2 * 3 * T, dtype=torch.float32).view(2, 3, T)
+        ch = chunk_spectogram(sp, size, ov)
+        assert len(ch) == int(cx[f'n.{ci}']) and [c.shape[-1] for c in ch] == cx[f'widths.{ci}'].tolist()
+        assert [float(c[0, 0, 0]) for c in ch] == cx[f'first.{ci}'].tolist()
+        assert np.allclose([float(c.double().sum()) for c in ch], cx[f'sum.{ci}'], rtol=0, atol=0)
     # chunk plan: valid frames of sample b in chunk ix == min(length_b + overlap - frames handed out before, width_ix)
     spec = torch.arange(3 * 2 * 1000, dtype=torch.float32).view(3, 2, 1000)
     lens = torch.tensor([1000, 530, 256])
@@ -303,3 +310,62 @@ def test_construction_seam_from_config(tmp_path):
     out = avg_all_models_in_dir(str(tmp_path), str(tmp_path / 'avg.pt'), model_name='step_5.pt')
     avg = torch.load(out, weights_only=True)
     assert torch.equal(avg['model']['w'], torch.full((2, 2), 2.0)) and avg['config'] == {'k': 0} and 'optimizer' not in avg
+
+
+def test_madgrad_anchor_is_created_at_the_first_step_not_at_construction(emulated_ops, monkeypatch):
+    """the reference creates x0 = clone(p) lazily at the first step (madgrad.py:121-125).  Weights loaded AFTER the
+    optimiser was built (load_checkpoint's non-strict branch, any model.load_state_dict) must be the anchor: one step from the
+    loaded weights equals the oracle's step from those weights."""
+    import lcasr_amd.optim as OPT
+    import kernel_refs
+    from oracle import madgrad_ref as M
+    monkeypatch.setattr(OPT, 'ops', kernel_refs)
+    g = torch.Generator().manual_seed(9)
+    lin = torch.nn.Linear(7, 5)
+    opt = OPT.MADGRAD(lin.parameters(), lr=3e-3)                 # built on the random init ...
+    new = {k: torch.randn(v.shape, generator=g) for k, v in lin.state_dict().items()}
+    lin.load_state_dict(new)                                     # ... then other weights arrive
+    grads = {k: torch.randn(v.shape, generator=g) * 0.1 for k, v in new.items()}
+    for k, p in lin.named_parameters(): p.grad.copy_(grads[k])
+    opt.step(max_norm=0.8)
+    coef, _ = M.clip_coef([v.numpy() for v in grads.values()], 0.8)
+    for k, p in lin.named_parameters():
+        p0 = new[k].numpy()
+        want, _, _ = M.madgrad_step(p0, grads[k].numpy() * np.float32(coef), np.zeros_like(p0), np.zeros_like(p0), p0, 0, 3e-3)
+        assert float(np.abs(p.detach().numpy() - want).max()) < 1e-6, k
+    assert opt.k == 1
+
+
+def test_madgrad_skipped_step_does_not_advance_k_and_frozen_parameters_are_left_alone(emulated_ops, monkeypatch):
+    """GradScaler skips optimizer.step() on inf/nan gradients, so the reference's state['k'] does not move
+    (exp/train.py:54-57); parameters without a gradient are skipped by the reference (madgrad.py:113-114)."""
+    import lcasr_amd.optim as OPT
+    import kernel_refs
+    monkeypatch.setattr(OPT, 'ops', kernel_refs)
+    a, b, frozen = (torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(3, 4)), torch.nn.Parameter(torch.randn(5), requires_grad=False))
+    f0 = frozen.detach().clone()
+    opt = OPT.MADGRAD([a, frozen, b], lr=1e-2, weight_decay=0.1)
+    assert [id(p) for p in opt.flat[0].params] == [id(a), id(b)] and frozen.grad is None
+    before = a.detach().clone()
+    a.grad.fill_(float('inf')); b.grad.fill_(1.0)
+    opt.step(max_norm=0.8)
+    assert opt.k == 0 and torch.equal(a.detach(), before)        # skipped: nothing moved, k did not advance
+    opt.zero_grad(); a.grad.fill_(0.5); b.grad.fill_(1.0)
+    opt.step(max_norm=0.8)
+    assert opt.k == 1 and not torch.equal(a.detach(), before)
+    assert torch.equal(frozen.detach(), f0)                       # neither decayed nor moved
+    sd = opt.state_dict()
+    assert sd['param_groups'][0]['params'] == [0, 1, 2] and sorted(k for k in sd['state'] if k != 'k') == [0, 2]
+    opt2 = OPT.MADGRAD([torch.nn.Parameter(a.detach().clone()), torch.nn.Parameter(f0.clone(), requires_grad=False),
+                        torch.nn.Parameter(b.detach().clone())], lr=1.0)
+    opt2.load_state_dict(sd)
+    assert opt2.k == 1 and torch.equal(opt2.param_groups[0]['_s'], opt.param_groups[0]['_s'])
+
+
+def test_decoder_refuses_class_counts_the_kernels_cannot_take():
+    """vocab_size + 1 must be a multiple of 16 on the HIP path; the constructor says so (the reference default
+    vocab_size=128 gives 129 classes)."""
+    from lcasr_amd.components.decoder import ASRLinearSCDecoder
+    with pytest.raises(ValueError, match='multiple of 16'):
+        ASRLinearSCDecoder(d_model=64, vocab_size=128)
+    assert ASRLinearSCDecoder(d_model=64, vocab_size=127).num_classes == 128

@@ -10,7 +10,7 @@ from oracle import ctc_ref, madgrad_ref
 from oracle import sconformer_ref as O
 
 
-@pytest.mark.parametrize('case', TINY_CASES)
+@pytest.mark.parametrize('case', TINY_CASES + ['tiny_ln_brn', 'tiny_ln_ckpt'])
 def test_oracle_matches_reference_fixture(case):
     fx = load_golden(case)
     sd = golden_state_dict(fx)
@@ -44,6 +44,32 @@ def test_oracle_c1_scalars():
                                          torch.from_numpy(fx['targets']), torch.from_numpy(fx['target_lengths']))
     assert abs(float(loss) - float(fx['loss'])) / float(fx['loss']) < 1e-5
     assert float((out['final_posteriors'][:, ::17, ::97] - torch.from_numpy(fx['logp_slice'])).abs().max()) < 5e-4
+
+
+def test_oracle_c2_scalars():
+    """BASELINE config 2 (6L/768D/6H, B=2, T=1024) from torch.manual_seed(12345): reference loss 1897.02."""
+    fx = load_golden('c2_scalars')
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    torch.manual_seed(12345)
+    sd = SCConformerXL(**golden_cfg(fx)).state_dict()
+    cfg = O.make_config(**golden_cfg(fx))
+    with torch.no_grad():
+        loss, _, out = O.train_step_loss(sd, cfg, torch.from_numpy(fx['x']), torch.from_numpy(fx['lengths']),
+                                         torch.from_numpy(fx['targets']), torch.from_numpy(fx['target_lengths']))
+    assert abs(float(loss) - float(fx['loss'])) / float(fx['loss']) < 1e-5
+    assert float((out['final_posteriors'][:, ::17, ::97] - torch.from_numpy(fx['logp_slice'])).abs().max()) < 1e-3
+
+
+def test_checkpoint_fixture_differs_from_plain_where_the_reference_does():
+    """tiny_ln_ckpt vs tiny_ln_brn (same weights / inputs, with and without checkpoint_every_n_layers=1 in the REFERENCE):
+    identical forward, BatchRenorm buffers moved twice instead of once, gradients of the recompute (different r / d clamps)."""
+    a, b = load_golden('tiny_ln_ckpt'), load_golden('tiny_ln_brn')
+    assert np.array_equal(a['logp'], b['logp']) and float(a['loss']) == float(b['loss'])
+    k = 'buf.layers.0.conv.fn.batch_norm.'
+    assert int(a[k + 'num_batches_tracked']) == 30002 and int(b[k + 'num_batches_tracked']) == 30001
+    assert float(np.abs(a[k + 'running_mean'] - b[k + 'running_mean']).max()) > 1e-3
+    gk = 'g.layers.0.conv.fn.pointwise_conv1.weight'
+    assert float(np.linalg.norm(a[gk] - b[gk]) / np.linalg.norm(b[gk])) > 1e-3
 
 
 def test_numpy_ctc_matches_torch_ctc():
