@@ -169,6 +169,47 @@ def run_case(SC, kw, B, T, lengths, tag, save_all_grads=True, save_weights=True,
     return model
 
 
+def bf16_noise_case(SC):
+    """What "bf16 tolerance" means for this model: the reference's OWN bf16-autocast path (exp/train.py:236, here
+    torch.autocast('cpu', bfloat16) - the CPU-runnable form of the same autocast policy) against its fp32 path, on the cases
+    the HIP path is checked on.  Stored: loss / log-prob differences and the per-tensor relative L2 of every gradient
+    (tests/common_model.py::rel_l2_errors).  The HIP path must not be noisier than this."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from common_model import rel_l2_errors
+    fx = {}
+    cases = {'tiny_ln_ragged': (dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200]),
+             'tiny_ln_equal': (dict(TINY, default_norm='layer_norm'), 2, 256, None),
+             'tiny_rms_ragged': (dict(TINY, default_norm='rms_norm'), 2, 256, [256, 200]),
+             'tiny_ln_odd': (dict(TINY, default_norm='layer_norm'), 3, 1000, [1000, 1023 - 40, 17 * 8]),
+             'c1_scalars': (C1, 2, 1024, None), 'c2_scalars': (C2, 2, 1024, None)}
+
+    def run(kw, B, T, lengths, bf16):
+        torch.manual_seed(12345)
+        m = SC(**kw); m.train()
+        x, ln, tg, tl = synth(B, T, kw['vocab_size'], lengths)
+        with torch.autocast('cpu', dtype=torch.bfloat16, enabled=bf16):
+            out = m(x, length=ln)
+            lp = out['final_posteriors']
+        loss = torch.nn.CTCLoss(blank=m.decoder.num_classes - 1, reduction='sum')(lp.float().transpose(0, 1), tg, out['length'], tl)
+        (loss / (T * B) * 100).backward()
+        return float(loss), lp.detach().float(), {k: p.grad.detach().float() for k, p in m.named_parameters()}
+
+    for tag, (kw, B, T, ln) in cases.items():
+        l0, lp0, g0 = run(kw, B, T, ln, False)
+        l1, lp1, g1 = run(kw, B, T, ln, True)
+        e = rel_l2_errors(g1, {k: v.numpy() for k, v in g0.items()})
+        d = (lp1 - lp0).abs()
+        names = sorted(e)
+        fx[tag + '.names'] = np.array(names)
+        fx[tag + '.grad_l2'] = np.array([e[k] for k in names])
+        fx[tag + '.loss_rel'] = np.float64(abs(l1 - l0) / l0)
+        fx[tag + '.logp_max'] = np.float64(float(d.max())); fx[tag + '.logp_mean'] = np.float64(float(d.mean()))
+        live = [e[k] for k in names if not k.endswith('depthwise_conv.bias')]
+        print(f'[bf16 noise of the reference, {tag}] loss rel {fx[tag + ".loss_rel"]:.2e}, log-prob max {float(d.max()):.3f} mean {float(d.mean()):.4f}, '
+              f'gradient rel-L2 median {np.median(live):.4f} worst {max(live):.4f}')
+    np.savez_compressed(os.path.join(GOLD, 'ref_bf16_noise.npz'), **fx)
+
+
 def chunk_case():
     """f2: `chunk_spectogram` (lcasr/utils/dataloading.py:14-25) run on integer-valued spectrograms.  The module's top-level
     imports need torchaudio (absent here), so the function's own definition is taken out of the file's syntax tree and
@@ -359,7 +400,12 @@ def main():
         run_case(SC, dict(TINY, default_norm='layer_norm', checkpoint_every_n_layers=1, ff_checkpoint_lvl=2), 2, 256, [256, 200],
                  'tiny_ln_ckpt', prep=perturb_brn)
         run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200], 'tiny_ln_brn', prep=perturb_brn)
+        bf16_noise_case(SC)
         return chunk_case()
+    if len(sys.argv) > 1 and sys.argv[1] == 'noise':
+        SC, _, _ = load_reference()
+        torch.set_num_threads(8)
+        return bf16_noise_case(SC)
     assert os.path.isdir(REF), 'reference not present: this script only runs in the development container'
     os.makedirs(GOLD, exist_ok=True)
     SC, attention_ref, MADGRAD = load_reference()
@@ -374,6 +420,7 @@ def main():
     run_case(SC, dict(TINY, default_norm='layer_norm', checkpoint_every_n_layers=1, ff_checkpoint_lvl=2), 2, 256, [256, 200],
              'tiny_ln_ckpt', prep=perturb_brn)
     run_case(SC, dict(TINY, default_norm='layer_norm'), 2, 256, [256, 200], 'tiny_ln_brn', prep=perturb_brn)
+    bf16_noise_case(SC)
     chunk_case()
     attention_cases(attention_ref)
     madgrad_case(MADGRAD)

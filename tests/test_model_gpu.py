@@ -15,12 +15,29 @@ import torch
 from common_model import (TINY_CASES, BlockCapture, build_from_fixture, grad_errors, rel_l2_errors, run_step, strided_like_fixture)
 from conftest import golden_cfg, load_golden
 
-# Gradient parity metric (round 2): per-tensor relative L2, ||g - ref|| / ||ref|| (common_model.rel_l2_errors).  Against the
-# reference's fp32 fixtures the error is bf16 storage noise carried through the stack: measured with the CPU emulation of the
-# same rounding points 0.02-0.035 median, 0.06-0.08 worst tensor on the 64-wide tiny model (the tensors behind a BatchRenorm,
-# which divides by a batch standard deviation and so amplifies the rounding of its input).  Bounds: worst tensor 0.12, median 0.05.
-# GPU against the CPU emulation of the same rounding points (accumulation order and fast exp/tanh only): worst 0.05.
-GRAD_L2_WORST, GRAD_L2_MEDIAN, GRAD_L2_VS_EMULATION = 0.12, 0.05, 0.05
+# Gradient parity metric (round 2): per-tensor relative L2, ||g - ref|| / ||ref|| (common_model.rel_l2_errors), against the
+# reference's fp32 gradients.  What bounds it is bf16 storage noise carried through the stack and amplified by every
+# BatchRenorm (a division by a batch standard deviation, and in the backward the removal of the mean and of the x-hat
+# component of the incoming gradient).  The calibration is the reference's OWN bf16-autocast path against its fp32 path on
+# the same cases (tests/golden/ref_bf16_noise.npz, oracle/make_golden.py::bf16_noise_case): median 0.04-0.09, worst live
+# tensor 0.14-0.17 on the tiny model and 0.66-0.75 at configs 1 / 2.  Measured here on MI355X: median 0.019-0.042, worst
+# 0.06-0.07 (tiny), 0.13 (c1), 0.11 (c2).  Bounds: worst tensor 0.15 AND below the reference's own worst; median 0.05 AND
+# below the reference's own median.  GPU against the CPU emulation of the same rounding points measures the SAME size as
+# either against fp32 (0.025 median / 0.07 worst): two bf16 evaluations that differ only in accumulation order are two
+# independent realisations of the rounding noise (an ulp flips where a value sits on a rounding boundary), not a tighter pair.
+GRAD_L2_WORST, GRAD_L2_MEDIAN, GRAD_L2_VS_EMULATION = 0.15, 0.05, 0.15
+
+
+def _check_grad_l2(tag, errs, noise_case=None):
+    _report(tag, errs)
+    worst, med = max(errs.values()), float(np.median(list(errs.values())))
+    assert worst < GRAD_L2_WORST and med < GRAD_L2_MEDIAN, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    if noise_case is not None:                                   # never noisier than the reference's own bf16 path
+        nz = load_golden('ref_bf16_noise')
+        theirs = dict(zip(nz[noise_case + '.names'].tolist(), nz[noise_case + '.grad_l2'].tolist()))
+        live = [v for k, v in theirs.items() if not k.endswith('depthwise_conv.bias')]
+        print(f'[{tag}] reference bf16-autocast vs its fp32: median {np.median(live):.4f}, worst {max(live):.4f}')
+        assert worst <= max(live) and med <= float(np.median(live)), (worst, max(live), med, float(np.median(live)))
 
 
 def _report(tag, errs):
@@ -48,9 +65,7 @@ def test_tiny_model_vs_reference_fixture(case):
     assert float(d.max()) < 0.35 and float(d.mean()) < 0.05, (float(d.max()), float(d.mean()))
     assert abs(r['loss'] - float(fx['loss'])) / float(fx['loss']) < 2e-3, (r['loss'], float(fx['loss']))
     errs = rel_l2_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')})
-    _report(case, errs)
-    assert max(errs.values()) < GRAD_L2_WORST and float(np.median(list(errs.values()))) < GRAD_L2_MEDIAN, \
-        sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_grad_l2(case, errs, noise_case=case)
     for k in fx.files:
         if k.startswith('buf.'):
             got = m.state_dict()[k[4:]].float().cpu()
@@ -163,9 +178,7 @@ def _check_scalar_fixture_grads(tag, fx, m):
     got = {k: strided_like_fixture(p.grad.detach().float().cpu(), cap) for k, p in m.named_parameters()}
     errs = rel_l2_errors(got, {k[3:]: fx[k] for k in fx.files if k.startswith('gs.')})
     assert len(errs) == len(list(m.parameters()))
-    _report(tag, errs)
-    assert max(errs.values()) < GRAD_L2_WORST and float(np.median(list(errs.values()))) < GRAD_L2_MEDIAN, \
-        sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    _check_grad_l2(tag, errs, noise_case=tag + '_scalars')
 
 
 def test_c2_config_from_seed():
@@ -232,8 +245,8 @@ def test_c4_shape_trainer_step_with_checkpointing_matches_plain():
     for extra in (dict(), dict(checkpoint_every_n_layers=1, ff_checkpoint_lvl=2)):
         torch.manual_seed(12345)
         m = SCConformerXL(**base, **extra).cuda().train()
-        tr = Trainer(m, lr=3e-3, global_batch=2)
-        batch = synthetic_batch(2, 4096, 4095, seed=5)
+        tr = Trainer(m, lr=3e-3, global_batch=4)
+        batch = synthetic_batch(4, 16384, 4095, seed=5)            # 8192 tokens: activations (not the 1.2 GB of state) set the peak
         torch.cuda.reset_peak_memory_stats()
         loss = float(tr.step(*batch))
         res.append((loss, tr.opt.flat[0].data.clone(), [int(l.conv.fn.batch_norm.num_batches_tracked) for l in m.layers],
