@@ -18,6 +18,7 @@
 //    no atomics, bitwise reproducible, at the price of recomputing S and dP once more.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -56,6 +57,8 @@ __device__ __forceinline__ BlkId decode_block(const AttnParams& p, int nx) {
     o.h = bh % p.H; o.b = bh / p.H;
     return o;
 }
+
+constexpr float RESCALE_LOG2 = 6.f;   // forward: rescale O / l only when a row's maximum has grown by more than 2^6 (see attn_fwd*_kernel)
 
 template <int D> __device__ __forceinline__ int tile_off(int row, int ch) {
     const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
@@ -129,23 +132,67 @@ __device__ __forceinline__ void glds_tile512(const bf16* base, long sn, int row0
     glds_tile_n<D, ROWS, 512>(base, sn, row0, nrows_valid, lds, tid);
 }
 
+// ---- LDS-DMA issued from inline asm ----------------------------------------------------------------------------------
+// hipcc cannot tell an LDS read from the destination of an in-flight global_load_lds issued through the builtin, so it puts
+// `s_waitcnt vmcnt(0)` in front of the first LDS read that follows one in program order: issued at the top of a stage, the next
+// stage's tile had to LAND before the current stage could be computed (60 % of the wave-cycles of the 8-wave dK/dV kernel were
+// parked there).  An asm statement is opaque to that bookkeeping: the 8-wave kernels below issue their DMA here, wait for it
+// themselves (`dma_wait_all` right before the barrier that publishes the stage) and leave every LDS READ to the compiler.
+// For that to work the loop must hold NO vector-memory operation the compiler knows of (the hardware counter is in order and
+// shared: any `s_waitcnt vmcnt(N)` it emits for a load of its own - a fragment loaded before the loop whose wait it sinks to the
+// first use, a spill reload, a per-stage statistics load - also waits for the DMA issued before it).
+// M0 carries the wave's LDS destination base and is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ void dma16_asm(const void* gsrc, unsigned lds_dst_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma4_asm(const void* gsrc, unsigned lds_dst_wave_base) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_wave_base) : "memory");
+}
+__device__ __forceinline__ void dma_wait_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(size_t)(const __attribute__((address_space(3))) char*)p;
+}
+// [ROWS][D] bf16 tile by asm DMA, NTHR threads; same swizzled image as glds_tile_n
+// `lds` = byte address of the tile in LDS as a wave-uniform (scalar) value
+template <int D, int ROWS, int NTHR>
+__device__ __forceinline__ void dma_tile(const bf16* base, long sn, int row0, int nrows_valid, unsigned lds, int tid) {
+    constexpr int CPR = D / 8, CHUNKS = ROWS * CPR, PER = CHUNKS / NTHR;
+    static_assert(CHUNKS % NTHR == 0, "tile must be whole passes of the workgroup");
+    const unsigned wbase = lds + (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        const int c = tid + NTHR * i;
+        const int row = c / CPR, pos = c % CPR;
+        const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+        const int gr = min(row0 + row, nrows_valid - 1);
+        dma16_asm(base + (long)gr * sn + (pos ^ swz) * 8, wbase + (unsigned)(NTHR * i) * 16u);
+    }
+}
+
+// make a fragment array's loads complete, as far as the compiler can tell, HERE (an empty asm that "rewrites" each register)
+template <int NF> __device__ __forceinline__ void pin_frags(bf16x8 (&f)[NF]) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) asm volatile("" : "+v"(f[i]));
+}
+__device__ __forceinline__ int opaque(int v) { asm volatile("" : "+v"(v)); return v; }
+
 // Loop-invariant per-lane LDS byte offsets.  tile_off's swizzle depends only on (row & 3) and ((row >> 2) & 3), so a
 // row base that is a multiple of 16 adds linearly (rbase * 2D) and every fragment read is "lane offset + constant":
 // the address math leaves the inner loops (it was ~8 VALU ops per ds_read, several hundred per MFMA block).
 template <int D> struct LaneOffs {
     int row[D / 16];                 // row form, k-step st
-    int trlo[D / 32], trhi[D / 32];  // transposed form, column block db (rows rb+4hh+q4 and +8)
+    int trlo[D / 32];                // transposed form, column block db, rows rb+4hh+q4; rows +8: (trlo ^ 32) + 16 D (frag_tr)
     __device__ __forceinline__ LaneOffs(int lane) {
 #pragma unroll
         for (int st = 0; st < D / 16; ++st) row[st] = tile_off<D>(lane & 31, 2 * st + (lane >> 5));
         const int i = lane & 15, q4 = i >> 2, p4 = i & 3, G = (lane >> 4) & 1, hh = lane >> 5;
         const int row0 = 4 * hh + q4, sub = (p4 & 1) * 8;
 #pragma unroll
-        for (int db = 0; db < D / 32; ++db) {
-            const int ch = db * 4 + 2 * G + (p4 >> 1);
-            trlo[db] = tile_off<D>(row0, ch) + sub;
-            trhi[db] = tile_off<D>(row0 + 8, ch) + sub;
-        }
+        for (int db = 0; db < D / 32; ++db) trlo[db] = tile_off<D>(row0, db * 4 + 2 * G + (p4 >> 1)) + sub;
     }
 };
 // A operand, row form: A[row = rbase + lane&31][k = 16*st + 8*hh + j]          (rbase % 16 == 0)
@@ -154,10 +201,13 @@ template <int D> __device__ __forceinline__ bf16x8 frag_row(const char* s, const
 }
 // A operand, transposed form: A[row = tile column db*32 + lane&31][k-slot j] where slot j of lane half hh is
 // tile row  rb + 8*(j>>2) + 4*hh + (j&3)  — the k order of a packed 32x32 accumulator (B operand).   (rb % 16 == 0)
-template <int D> __device__ __forceinline__ bf16x8 frag_tr(const char* s, const LaneOffs<D>& L, int rb, int db) {
+// The second half (tile rows +8) needs no offset table of its own: 8 rows further the swizzle's low chunk bits are flipped by 2
+// (tile_off: ((row >> 2) & 3) ^ 2), i.e. the byte offset is (trlo ^ 32) + 8 rows.  `x32` is that 32: callers short of registers
+// pass an opaque copy made inside their loop, so that hipcc cannot hoist the D/32 derived offsets back into live registers.
+template <int D> __device__ __forceinline__ bf16x8 frag_tr(const char* s, const LaneOffs<D>& L, int rb, int db, int x32 = 32) {
     typedef __attribute__((address_space(3))) bf16x4* lds_p;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + rb * 2 * D + L.trlo[db]));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + rb * 2 * D + L.trhi[db]));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_p)(s + rb * 2 * D + 16 * D + (L.trlo[db] ^ x32)));
     return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
 }
 // B operand straight from global: B[k = 16*st + 8*hh + j][col = lane&31] = X[row0 + lane&31][d]
@@ -262,21 +312,28 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float mu = (mn == -INFINITY) ? 0.f : mn;
-        const float alpha = __builtin_amdgcn_exp2f((m - mu) * c);
-        const float mc = mu * c;
+        // Deferred rescale: m is the reference point of the exponentials, not necessarily the running maximum.  It moves (and
+        // O, l are rescaled: 64 + 1 multiplies per lane) only when some row of the wave has outgrown it by more than 2^RESCALE_LOG2;
+        // until then P <= 2^RESCALE_LOG2 instead of <= 1, which costs nothing (bf16 P keeps its relative precision, O and l stay
+        // far inside f32 range) and O / l at the end is the same quotient.  The softmax VALU work is as long as the tile's
+        // MFMAs here, so the skipped rescale is time, not just instructions.
+        if (__any((mx - m) * c > RESCALE_LOG2)) {            // wave-uniform; also the first tile of every row (m = -inf)
+            const float mn = fmaxf(m, mx);
+            const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m - mn) * c);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float mc = (m == -INFINITY) ? 0.f : m * c;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] * c - mc); s[kt][r] = e; rs += e; }
-        l = l * alpha + rs;
-        m = mn;
-#pragma unroll
-        for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l += rs;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { pf[kt][0] = pack8(s[kt], 0); pf[kt][1] = pack8(s[kt], 1); }
@@ -330,16 +387,21 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
     float m = -INFINITY, l = 0.f;
 
-    if (t_lo < t_hi) { glds_tile_n<D, KT, 512>(kp, p.k_sn, t_lo * KT, p.N, smem, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, t_lo * KT, p.N, smem + TB, tid); }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int t, int buf) {                     // K | V stage by asm-issued LDS-DMA (invisible to hipcc's vmcnt bookkeeping)
+        const int tid_ = opaque(tid);                      // offsets recomputed per stage: kept live across the loop they would be spilled
+        dma_tile<D, KT, 512>(kp, p.k_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB), tid_);
+        dma_tile<D, KT, 512>(vp, p.v_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB + TB), tid_);
+    };
+    if (t_lo < t_hi) issue(t_lo, 0);
+    pin_frags(qf);
+    dma_wait_all();
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sK = smem + cur * 2 * TB;
         const char* sV = sK + TB;
-        if (t + 1 < t_hi) {                                  // next K/V tile streams into the other buffer during this tile
-            char* dK = smem + (cur ^ 1) * 2 * TB;
-            glds_tile_n<D, KT, 512>(kp, p.k_sn, (t + 1) * KT, p.N, dK, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, (t + 1) * KT, p.N, dK + TB, tid);
-        }
+        if (t + 1 < t_hi) issue(t + 1, cur ^ 1);             // next K/V tile streams into the other buffer during this tile
         for (int half = 0; half < KT / 64; ++half) {
         const int kv0 = t * KT + half * 64;
         if (kv0 >= kv_hi) break;                           // uniform: the second half of the last stage may be past the keys
@@ -347,12 +409,25 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
         const char* sVh = sV + half * 64 * 2 * D;
         f32x16 s[2];
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kt][r] = 0.f;
+        {   // S^T = K Q^T: 16 (K row fragment, MFMA) pairs, fragments requested PF pairs ahead.  Left alone hipcc reuses ONE
+            // destination register set (read -> lgkmcnt(0) -> MFMA, the LDS latency exposed 16 times); the order is pinned with
+            // sched_group_barrier (mask 0x100 = LDS read, 0x008 = MFMA).
+            constexpr int NP = 2 * (D / 16), PF = 3;
+            bf16x8 ka[NP];
 #pragma unroll
-            for (int st = 0; st < D / 16; ++st)
-                s[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sKh, L, kt * 32, st), qf[st], s[kt], 0, 0, 0);
+            for (int i = 0; i < PF; ++i) ka[i] = frag_row<D>(sKh, L, (i / (D / 16)) * 32, i % (D / 16));
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                if (i + PF < NP) ka[i + PF] = frag_row<D>(sKh, L, ((i + PF) / (D / 16)) * 32, (i + PF) % (D / 16));
+                s[i / (D / 16)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[i], qf[i % (D / 16)], s[i / (D / 16)], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, PF, 0);
+#pragma unroll
+            for (int i = 0; i < NP - PF; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         }
         if (kv0 + 64 > kv_hi || windowed) {
 #pragma unroll
@@ -372,32 +447,48 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float mn = fmaxf(m, mx);
-        const float mu = (mn == -INFINITY) ? 0.f : mn;
-        const float alpha = __builtin_amdgcn_exp2f((m - mu) * c);
-        const float mc = mu * c;
+        // Deferred rescale: m is the reference point of the exponentials, not necessarily the running maximum.  It moves (and
+        // O, l are rescaled: 64 + 1 multiplies per lane) only when some row of the wave has outgrown it by more than 2^RESCALE_LOG2;
+        // until then P <= 2^RESCALE_LOG2 instead of <= 1, which costs nothing (bf16 P keeps its relative precision, O and l stay
+        // far inside f32 range) and O / l at the end is the same quotient.  The softmax VALU work is as long as the tile's
+        // MFMAs here, so the skipped rescale is time, not just instructions.
+        if (__any((mx - m) * c > RESCALE_LOG2)) {            // wave-uniform; also the first tile of every row (m = -inf)
+            const float mn = fmaxf(m, mx);
+            const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m - mn) * c);
+            l *= alpha;
+            m = mn;
+#pragma unroll
+            for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        }
+        const float mc = (m == -INFINITY) ? 0.f : m * c;
         float rs = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(s[kt][r] * c - mc); s[kt][r] = e; rs += e; }
-        l = l * alpha + rs;
-        m = mn;
-#pragma unroll
-        for (int i = 0; i < D / 32; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+        l += rs;
         bf16x8 pf[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) { pf[kt][0] = pack8(s[kt], 0); pf[kt][1] = pack8(s[kt], 1); }
+        {   // O^T += V^T P^T: 16 (transposed V fragment = 2 tr reads, MFMA) pairs, same pinned pipeline
+            constexpr int NP = 4 * (D / 32), PF = 2;
+            bf16x8 va[NP];
 #pragma unroll
-        for (int db = 0; db < D / 32; ++db)
+            for (int i = 0; i < PF; ++i) va[i] = frag_tr<D>(sVh, L, ((i >> 1) & 1) * 32 + 16 * (i & 1), i >> 2);
 #pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
+            for (int i = 0; i < NP; ++i) {
+                if (i + PF < NP) { const int j = i + PF; va[j] = frag_tr<D>(sVh, L, ((j >> 1) & 1) * 32 + 16 * (j & 1), j >> 2); }
+                o[i >> 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va[i], pf[(i >> 1) & 1][i & 1], o[i >> 2], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * PF, 0);
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2)
-                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, kt * 32 + 16 * s2, db), pf[kt][s2], o[db], 0, 0, 0);
+            for (int i = 0; i < NP - PF; ++i) { __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); }
+            __builtin_amdgcn_sched_group_barrier(0x008, PF, 0);
         }
+        }
+        dma_wait_all();                                      // the next stage has landed (issued a stage of MFMAs ago)
         __syncthreads();
     }
     const float lt = l + __shfl_xor(l, 32, 64);
@@ -586,9 +677,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
     load_bfrags<D>(kf, kp, p.k_sn, k0, p.N, lane);
     const LaneOffs<D> L(lane);
     char* sVt = smem + 2 * SB;
-    glds_tile512<D, 256>(vp, p.v_sn, kb0, p.N, sVt, tid);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    dma_tile<D, 256, 512>(vp, p.v_sn, kb0, p.N, lds0 + (unsigned)(2 * SB), tid);
     const char* sVw = sVt + wave * 32 * 2 * D;
-    const bool need_mask = p.win_left >= 0 || p.win_right >= 0 || kb0 + 256 > len;   // uniform per workgroup
+    const bool mask_wg = p.win_left >= 0 || p.win_right >= 0 || kb0 + 256 > len;     // uniform per workgroup
 
     const int q_lo = p.win_right < 0 ? 0 : max(0, kb0 - p.win_right);
     const int q_hi = min(len, p.win_left < 0 ? len : kb0 + 256 + p.win_left);
@@ -600,17 +692,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkt[i][r] = 0.f; dvt[i][r] = 0.f; }
 
-    float st_l = 0.f, st_d = 0.f;
-    auto gload_stats = [&](int q0) {
-        if (tid < QR) { const int q = q0 + tid; st_l = (q < len) ? lsep[q] * 1.4426950408889634f : INFINITY; st_d = (q < len) ? delp[q] : 0.f; }
+    // a stage = Q | dO | lse[64] | delta[64], all by asm-issued LDS-DMA (the statistics as two 4-byte-per-lane pieces): the loop
+    // holds no vector-memory operation the compiler knows of, so none of its waits can drain the DMA in flight
+    auto issue = [&](int t, int buf) {
+        const int tid_ = opaque(tid);                      // offsets recomputed per stage: kept live across the loop they would be spilled
+        dma_tile<D, QR, 512>(qp, p.q_sn, t * QR, p.N, lds0 + (unsigned)(buf * SB), tid_);
+        dma_tile<D, QR, 512>(gp, p.do_sn, t * QR, p.N, lds0 + (unsigned)(buf * SB + TB), tid_);
+        const int wave_u = __builtin_amdgcn_readfirstlane(tid_ >> 6);    // scalar: the pointer select below stays in SGPRs
+        if (wave_u < 2) {                                  // wave 0: lse, wave 1: delta; rows past the tensor are clamped and masked below
+            const int q = min(t * QR + (tid_ & 63), p.N - 1);
+            dma4_asm((wave_u == 0 ? lsep : delp) + q, lds0 + (unsigned)(buf * SB + 2 * TB) + 256u * (unsigned)wave_u);
+        }
     };
-    auto lstore_stats = [&](char* s) {
-        if (tid < QR) { reinterpret_cast<float*>(s + 2 * TB)[tid] = st_l; reinterpret_cast<float*>(s + 2 * TB + 256)[tid] = st_d; }
-    };
-    if (t_lo < t_hi) {
-        glds_tile512<D, QR>(qp, p.q_sn, t_lo * QR, p.N, smem, tid); glds_tile512<D, QR>(gp, p.do_sn, t_lo * QR, p.N, smem + TB, tid);
-        gload_stats(t_lo * QR); lstore_stats(smem);
-    }
+    if (t_lo < t_hi) issue(t_lo, 0);
+    pin_frags(kf);
+    dma_wait_all();
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
@@ -618,11 +714,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
         const char* sG = sQ + TB;
         const float* sL = reinterpret_cast<const float*>(sQ + 2 * TB);
         const float* sD = sL + 64;
-        if (t + 1 < t_hi) {
-            char* dS = smem + (cur ^ 1) * SB;
-            glds_tile512<D, QR>(qp, p.q_sn, (t + 1) * QR, p.N, dS, tid); glds_tile512<D, QR>(gp, p.do_sn, (t + 1) * QR, p.N, dS + TB, tid);
-            gload_stats((t + 1) * QR);
-        }
+        if (t + 1 < t_hi) issue(t + 1, cur ^ 1);
+        const bool need_mask = mask_wg || (t + 1) * QR > len;                         // uniform
+        const int x32 = opaque(32);                    // see frag_tr: keeps 4 derived offsets out of the (full) register file
+        const int hh = (opaque(tid) >> 5) & 1;         // re-derived per stage for the same reason (shadows the kernel-scope hh)
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {            // two 32-query sub-tiles per stage
             const int rb = 32 * sub, q0 = t * QR + rb;
@@ -638,14 +733,15 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
             for (int g = 0; g < 4; ++g) {
                 const float4 a = *reinterpret_cast<const float4*>(sL + rb + 8 * g + 4 * hh);
                 const float4 b_ = *reinterpret_cast<const float4*>(sD + rb + 8 * g + 4 * hh);
-                const float la[4] = {a.x, a.y, a.z, a.w}, da[4] = {b_.x, b_.y, b_.z, b_.w};
+                constexpr float LOG2E = 1.4426950408889634f;
+                const float la[4] = {a.x * LOG2E, a.y * LOG2E, a.z * LOG2E, a.w * LOG2E}, da[4] = {b_.x, b_.y, b_.z, b_.w};
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
                     bool ok = true;
                     if (need_mask) {
                         const int q = q0 + acc_row(r, hh);
-                        ok = key < len;
+                        ok = key < len && q < len;
                         if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
                         if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
                     }
@@ -657,13 +753,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
             const bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb, db), pb0, dvt[db], 0, 0, 0);
-                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb + 16, db), pb1, dvt[db], 0, 0, 0);
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb, db), db0, dkt[db], 0, 0, 0);
-                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb + 16, db), db1, dkt[db], 0, 0, 0);
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb, db, x32), pb0, dvt[db], 0, 0, 0);
+                dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb + 16, db, x32), pb1, dvt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb, db, x32), db0, dkt[db], 0, 0, 0);
+                dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb + 16, db, x32), db1, dkt[db], 0, 0, 0);
             }
         }
-        if (t + 1 < t_hi) lstore_stats(smem + (cur ^ 1) * SB);
+        dma_wait_all();                                // the next stage has landed (issued a stage of MFMAs ago)
         __syncthreads();
     }
     if (key < p.N) {
@@ -789,16 +885,21 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
 
-    if (t_lo < t_hi) { glds_tile_n<D, KT, 512>(kp, p.k_sn, t_lo * KT, p.N, smem, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, t_lo * KT, p.N, smem + TB, tid); }
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    auto issue = [&](int t, int buf) {                     // K | V stage by asm-issued LDS-DMA (see dma16_asm)
+        const int tid_ = opaque(tid);
+        dma_tile<D, KT, 512>(kp, p.k_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB), tid_);
+        dma_tile<D, KT, 512>(vp, p.v_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB + TB), tid_);
+    };
+    if (t_lo < t_hi) issue(t_lo, 0);
+    pin_frags(qf); pin_frags(gf);
+    dma_wait_all();
     __syncthreads();
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sK = smem + cur * 2 * TB;
         const char* sV = sK + TB;
-        if (t + 1 < t_hi) {
-            char* dK = smem + (cur ^ 1) * 2 * TB;
-            glds_tile_n<D, KT, 512>(kp, p.k_sn, (t + 1) * KT, p.N, dK, tid); glds_tile_n<D, KT, 512>(vp, p.v_sn, (t + 1) * KT, p.N, dK + TB, tid);
-        }
+        if (t + 1 < t_hi) issue(t + 1, cur ^ 1);
         const int kv0 = t * KT;
 #pragma unroll
         for (int kt = 0; kt < KT / 32; ++kt) {
@@ -830,6 +931,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
                 dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32 + 16, db), d1, dqt[db], 0, 0, 0);
             }
         }
+        dma_wait_all();
         __syncthreads();
     }
     if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
