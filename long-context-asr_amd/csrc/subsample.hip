@@ -534,6 +534,14 @@ __global__ __launch_bounds__(256) void stage01_bwd_kernel(const TX* __restrict__
     fused_reduce<1>(gbd, g, C, red, dbd, 1);
 }
 
+}  // namespace
+// subsample_mfma.hip: conv0 on the matrix cores; return 1 when they took the problem
+int sconf_stage01_fwd_mfma(const void* x, int x_dtype, const float* w0, const float* b0, const float* wd, const float* bd, void* d1,
+                           int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream);
+int sconf_stage01_bwd_mfma(const void* dd1, const void* x, int x_dtype, const float* w0, const float* b0, const float* wd,
+                           float* dw0, float* db0, float* dwd, float* dbd, int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream);
+namespace {
+
 struct LaunchGeo { int PL, iters, threads; dim3 grid; };
 // npos positions per batch item; aim for ~target workgroups in total.
 inline LaunchGeo geo_for(int64_t C, int64_t B, long npos, long target_blocks) {
@@ -636,6 +644,7 @@ SCONF_API int sconf_sub_stage01_fwd(const void* x, int x_dtype, const float* w0,
     SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_fwd: B <= 65535 and F <= 1024");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
     if (B * T4 * F4 == 0) return 0;
+    if (sconf_stage01_fwd_mfma(x, x_dtype, w0, b0, wd, bd, d1, B, F, T, C, stream)) { SCONF_LAUNCH_OK("sconf_sub_stage01_fwd"); return 0; }
     long target = 4096;
     if (const char* e = getenv("SCONF_SUB_FWD_BLOCKS")) target = atol(e);                       // tuning
     const int rpb = std::max(1, (int)cdiv((long)T4 * B, target));
@@ -663,6 +672,7 @@ SCONF_API int sconf_sub_stage01_bwd(const void* dd1, const void* x, int x_dtype,
     SCONF_REQUIRE(B <= 65535 && F <= 1024, "sconf_sub_stage01_bwd: B <= 65535 and F <= 1024");
     const int T2 = (int)((T - 1) / 2 + 1), F2 = (int)((F - 1) / 2 + 1), T4 = (T2 - 1) / 2 + 1, F4 = (F2 - 1) / 2 + 1;
     if (B * T4 * F4 == 0) return 0;
+    if (sconf_stage01_bwd_mfma(dd1, x, x_dtype, w0, b0, wd, dw0, db0, dwd, dbd, B, F, T, C, stream)) { SCONF_LAUNCH_OK("sconf_sub_stage01_bwd"); return 0; }
     int rw = 4; long target = 512;                             // measured best of {1,2,4} x {256..2048} at config 3
     if (const char* e = getenv("SCONF_SUB_BWD_CFG")) { int a = 0; long t = 0; if (sscanf(e, "%d,%ld", &a, &t) == 2) { rw = a; target = t; } }   // tuning
     auto lds_bytes = [&](int r) { return (size_t)((2 * r + 1) * F + 256) * 4 + (size_t)(r / 2 + 2) * F4 * C * 2; };
