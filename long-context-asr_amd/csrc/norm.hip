@@ -252,34 +252,27 @@ __global__ __launch_bounds__(1024) void norm_bwd_reduce_kernel(const float* __re
     }
 }
 
-// Launch geometry of the backward: NB_WAVES waves per workgroup, <= MAXG workgroups (each wave walks rows wid, wid + nw, ...).
-struct BwdGeo { int nbw, maxg; bool ahead; };
-static BwdGeo bwd_geo(int nit) {
+// Launch geometry of the backward: 8 waves per workgroup, <= one workgroup per CU (each wave walks rows wid, wid + nw, ...); the next
+// row's loads are issued a row ahead when the row fits the register file (d <= 1024).  Both were run-time template choices in round 1
+// (x 4 instantiations of every (mode, width, dtype) combination: a 10 MB object for a LayerNorm); the measured-best pair is now fixed.
+constexpr int NBW = 8;
+static int bwd_maxgrid() {
     static int cus = 0;
     if (!cus) { const int n = sconf_num_cus(); cus = n > 0 ? n : 256; }
-    BwdGeo g{8, cus, nit <= 4};                       // one workgroup per CU (measured best: 8 waves, next row in flight);
-                                                      // wider rows would spill with a row in flight: load where used
-    if (const char* e = getenv("SCONF_NORM_BWD_CFG")) {      // "waves,maxgrid,ahead" (benchmarking)
-        int a = 8, b = 512, c = 1;
-        if (sscanf(e, "%d,%d,%d", &a, &b, &c) == 3) { g.nbw = a == 4 ? 4 : 8; g.maxg = b; g.ahead = c && nit <= 4; }
-    }
-    return g;
+    if (const char* e = getenv("SCONF_NORM_BWD_GRID")) { const int v = atoi(e); if (v > 0) return v; }      // benchmarking
+    return cus;
 }
 
 template <int MODE, int NIT>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
                const float* dres, void* dx, int odt, float* dw, float* db, float* ws, long ws_floats, bf16* dx16, float* dx_colsum,
                int M, int d, float eps, hipStream_t st) {
-    const BwdGeo geo = bwd_geo(NIT);
-    dim3 grid(min(cdiv(M, geo.nbw), geo.maxg)), block(64 * geo.nbw);
+    constexpr bool AHEAD = NIT <= 4;
+    dim3 grid(min(cdiv(M, NBW), bwd_maxgrid())), block(64 * NBW);
     const bool slab = ws && ws_floats >= (long)grid.x * 3 * d;
     if (!slab) { dx16 = nullptr; dx_colsum = nullptr; }
-#define L4(TI, TG, TO, NBW, AH, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AH, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, dx16, M, d, eps)
-#define L(TI, TG, TO) do { \
-    if (geo.nbw == 8) { if (geo.ahead) { if (slab) L4(TI, TG, TO, 8, true, true); else L4(TI, TG, TO, 8, true, false); } \
-                        else           { if (slab) L4(TI, TG, TO, 8, false, true); else L4(TI, TG, TO, 8, false, false); } } \
-    else              { if (geo.ahead) { if (slab) L4(TI, TG, TO, 4, true, true); else L4(TI, TG, TO, 4, true, false); } \
-                        else           { if (slab) L4(TI, TG, TO, 4, false, true); else L4(TI, TG, TO, 4, false, false); } } } while (0)
+#define L4(TI, TG, TO, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AHEAD, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, dx16, M, d, eps)
+#define L(TI, TG, TO) do { if (slab) L4(TI, TG, TO, true); else L4(TI, TG, TO, false); } while (0)
     if (xdt == SCONF_F32) {
         if (gdt == SCONF_F32) { if (odt == SCONF_F32) L(float, float, float); else L(float, float, bf16); }
         else                  { if (odt == SCONF_F32) L(float, bf16, float);  else L(float, bf16, bf16); }
@@ -319,8 +312,7 @@ SCONF_API int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* 
 // sconf_norm_bwd_workspace(M, d) floats, contents irrelevant) receives per-workgroup column sums that a second kernel adds
 // into dweight/dbias in a fixed order; without it the workgroups fall back to f32 atomics (slower, order not fixed).
 SCONF_API int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d) {
-    const BwdGeo geo = bwd_geo((int)((d + 255) / 256));
-    return (int64_t)min(cdiv(M, geo.nbw), geo.maxg) * 3 * d;
+    return (int64_t)min(cdiv(M, NBW), bwd_maxgrid()) * 3 * d;
 }
 SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                              const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype,

@@ -6,7 +6,7 @@ import lcasr_amd.hip.ops as ops
 from bench import CONFIGS
 from lcasr_amd.models.sconformer_xl import SCConformerXL
 from lcasr_amd.train import Trainer, synthetic_batch
-cfg = CONFIGS['c3']; B = 16
+cfg = CONFIGS["c3"]; B = int(os.environ.get("GB", "16"))
 torch.manual_seed(12345)
 model = SCConformerXL(**cfg['model']).cuda().train()
 tr = Trainer(model, global_batch=B)

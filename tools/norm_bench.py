@@ -24,6 +24,6 @@ print(f'norm_fwd f32->bf16: {us:7.1f} us  {M*d*6/us/1e6:6.2f} TB/s')
 if len(sys.argv) > 1:
     dy = torch.randn(M, d, device='cuda').bfloat16()
     for cfg in sys.argv[1:]:
-        os.environ['SCONF_NORM_BWD_CFG'] = cfg
+        os.environ['SCONF_NORM_BWD_GRID'] = cfg            # max workgroups
         us = timeit(lambda: ops.norm_bwd(dy, x, w, mean, rstd, 'layer_norm', 1e-5, dres, torch.float32, dw, db))
         print(f'cfg {cfg:12s}: {us:7.1f} us  {M*d*14/us/1e6:6.2f} TB/s')
