@@ -65,7 +65,8 @@ int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t
 /* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */
 int sconf_cast_transpose(const float* src, void* dst, int64_t R, int64_t C, sconf_stream_t stream);
 /* One launch for all bf16 weight shadows of a model.  table: device array of n_entries + 1 records of six int64
- * {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R, C, first 32x32-tile index}; the last record is the sentinel
+ * {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R (negative: |R| rows, written regrouped 3j + w -> w |R|/3 + j: the
+ * "(h d qkv)" rows of the fused qkv projection, attention.py:485, as [q | k | v]), C, first 32x32-tile index}; the last record is the sentinel
  * {0,0,0,0,0,total_tiles}.  Stands in for the per-module weight casts torch.autocast does in the reference
  * (lcasr/utils/general.py, training loop under autocast) plus the transposed copies the NT dgrad GEMMs read. */
 int sconf_cast_shadows(const void* table, int64_t n_entries, int64_t total_tiles, sconf_stream_t stream);
@@ -74,6 +75,11 @@ int sconf_cast_shadows(const void* table, int64_t n_entries, int64_t total_tiles
  * bwd != 0: transpose, (dq,dk,dv) -> dqkv written to `qkv`.  cos/sin: f32 [N][D/2]. */
 int sconf_rotary_qkv(int bwd, void* qkv, const float* cos_tab, const float* sin_tab, void* q, void* k, void* v,
                      int64_t B, int64_t N, int64_t H, int64_t D, int use_rotary, sconf_stream_t stream);
+/* The fused path of round 2: the qkv weight SHADOW is written regrouped (sconf_cast_shadows, R < 0: row 3j + w -> w * R/3 + j), so
+ * the qkv GEMM already emits (B*N, 3, H, D) = [q | k | v] and no de-interleave pass exists; apply_rotary_pos_emb
+ * (rotary_emb.py:61-73) is applied in place to the q and k blocks, and its transpose inside sconf_attn_bwd (rot_cos / rot_sin). */
+int sconf_rotary_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t B, int64_t N, int64_t H, int64_t D,
+                         sconf_stream_t stream);
 
 /* mode 0 softmax (sconformer_xl.py:242), mode 1 log_softmax (decoder.py:25); C <= 8192 classes. */
 int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, int y_dtype, int64_t M, int64_t C, sconf_stream_t stream);
@@ -100,7 +106,9 @@ int sconf_attn_bwd(const void* q, const void* k, const void* v, const void* o, c
                    float* delta, void* dq, void* dk, void* dv, const int32_t* lengths, int64_t B, int64_t N, int64_t H,
                    int64_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                    const int64_t* o_strides, const int64_t* do_strides, const int64_t* dq_strides, const int64_t* dk_strides,
-                   const int64_t* dv_strides, int win_left, int win_right, float scale, sconf_stream_t stream);
+                   const int64_t* dv_strides, int win_left, int win_right, float scale,
+                   const float* rot_cos /*nullable: f32 (N, D/2); with rot_sin: dq, dk come back as gradients of the UNROTATED q, k*/,
+                   const float* rot_sin, sconf_stream_t stream);
 
 /* Conformer conv module, token-major (convolution.py:103-124; conv1dFunc seam convolution.py:6-22; batchrenorm.py:52-92). */
 int sconf_glu_dwconv_fwd(const void* g, const int32_t* lengths, const float* w, const float* bias, void* h, double* stats,

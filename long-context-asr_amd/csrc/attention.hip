@@ -36,6 +36,7 @@ struct AttnParams {
     int win_left, win_right;          // -1 = unbounded
     float scale;                      // 1/sqrt(D)
     int xcd_remap;                    // 1: XCD-contiguous workgroup order (decode_block)
+    const float *rot_cos, *rot_sin;   // backward: (N, D/2) rotary tables or null - dq, dk are returned as gradients of the UNROTATED q, k
 };
 
 // Workgroup -> (batch, head, row block) for a 1-D launch of nx * H * B workgroups.  The hardware deals consecutive workgroup ids
@@ -239,6 +240,42 @@ template <int D> __device__ __forceinline__ void store_t(const f32x16 (&acc)[D /
             for (int e = 0; e < 4; ++e) v[e] = acc[db][4 * r4 + e] * sc;
             store4(dst_row + db * 32 + 8 * r4 + 4 * hh, v);
         }
+}
+
+// The same store with the transpose of the NeoX rotation applied first: acc is the gradient with respect to the ROTATED q (or k) of
+// row n; what is stored is the gradient with respect to the unrotated one (rotary_emb.py:61-73):
+//     g[d] = g'[d] cos + g'[d + D/2] sin,   g[d + D/2] = g'[d + D/2] cos - g'[d] sin        (d < D/2, cos/sin at (n, d)).
+// Both partners sit in the same lane: d = 32 db + acc_row(r, hh), so d + 64 is accumulator block db + 2 (D = 128) and d + 16 is
+// register r + 8 (D = 32).  This replaces the separate (dq, dk, dv) -> dqkv rotary pass over the activations.
+template <int D> __device__ __forceinline__ void store_t_rot(f32x16 (&acc)[D / 32], bf16* dst_row, float sc, int hh, const float* cs, const float* sn) {
+    if constexpr (D == 128) {
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                float c[4], s[4];
+                load4(cs + db * 32 + 8 * r4 + 4 * hh, c); load4(sn + db * 32 + 8 * r4 + 4 * hh, s);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float a = acc[db][4 * r4 + e], b = acc[db + 2][4 * r4 + e];
+                    acc[db][4 * r4 + e] = a * c[e] + b * s[e];
+                    acc[db + 2][4 * r4 + e] = b * c[e] - a * s[e];
+                }
+            }
+    } else {
+#pragma unroll
+        for (int r4 = 0; r4 < 2; ++r4) {
+            float c[4], s[4];
+            load4(cs + 8 * r4 + 4 * hh, c); load4(sn + 8 * r4 + 4 * hh, s);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float a = acc[0][4 * r4 + e], b = acc[0][4 * r4 + 8 + e];
+                acc[0][4 * r4 + e] = a * c[e] + b * s[e];
+                acc[0][4 * r4 + 8 + e] = b * c[e] - a * s[e];
+            }
+        }
+    }
+    store_t<D>(acc, dst_row, sc, hh);
 }
 
 // =============================================================================================
@@ -644,8 +681,9 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
         __syncthreads();
     }
     if (key < p.N) {
-        store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, hh);
-        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, hh);
+        if (p.rot_cos) store_t_rot<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5, p.rot_cos + (long)key * (D / 2), p.rot_sin + (long)key * (D / 2));
+        else store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5);
+        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, lane >> 5);
     }
 }
 
@@ -763,8 +801,9 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
         __syncthreads();
     }
     if (key < p.N) {
-        store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, hh);
-        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, hh);
+        if (p.rot_cos) store_t_rot<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5, p.rot_cos + (long)key * (D / 2), p.rot_sin + (long)key * (D / 2));
+        else store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5);
+        store_t<D>(dvt, p.dv + b * p.dv_sb + (long)key * p.dv_sn + h * p.dv_sh, 1.f, lane >> 5);
     }
 }
 
@@ -847,7 +886,10 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
         }
         __syncthreads();
     }
-    if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+    if (qi < p.N) {
+        if (p.rot_cos) store_t_rot<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh, p.rot_cos + (long)qi * (D / 2), p.rot_sin + (long)qi * (D / 2));
+        else store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+    }
 }
 
 // 8-wave form of the dQ kernel (D = 128): 256 queries per workgroup, 128-key stages shared by 8 waves (see attn_bwd_dkdv8_kernel)
@@ -934,7 +976,10 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
         dma_wait_all();
         __syncthreads();
     }
-    if (qi < p.N) store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+    if (qi < p.N) {
+        if (p.rot_cos) store_t_rot<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh, p.rot_cos + (long)qi * (D / 2), p.rot_sin + (long)qi * (D / 2));
+        else store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
+    }
 }
 
 void set_lds_attrs() {
@@ -988,13 +1033,15 @@ SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* 
     return 0;
 }
 
-// Backward.  delta: f32 (B,H,N) scratch.  dq/dk/dv: bf16 strided like q/k/v.
+// Backward.  delta: f32 (B,H,N) scratch.  dq/dk/dv: bf16 strided like q/k/v.  rot_cos / rot_sin (nullable, f32 (N, D/2)): q and k
+// are rotary-rotated activations; dq and dk are then returned with the transpose of the rotation applied, i.e. as gradients of
+// the unrotated projections (apply_rotary_pos_emb backward, rotary_emb.py:61-73).
 SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
                              float* delta, void* dq, void* dk, void* dv, const int32_t* lengths,
                              int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* q_strides, const int64_t* k_strides,
                              const int64_t* v_strides, const int64_t* o_strides, const int64_t* do_strides,
                              const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides,
-                             int win_left, int win_right, float scale, hipStream_t stream) {
+                             int win_left, int win_right, float scale, const float* rot_cos, const float* rot_sin, hipStream_t stream) {
     int64_t all[24];
     const int64_t* ss[8] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
     for (int j = 0; j < 8; ++j) for (int i = 0; i < 3; ++i) all[3 * j + i] = ss[j][i];
@@ -1011,6 +1058,8 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
     p.dk_sb = dk_strides[0]; p.dk_sn = dk_strides[1]; p.dk_sh = dk_strides[2];
     p.dv_sb = dv_strides[0]; p.dv_sn = dv_strides[1]; p.dv_sh = dv_strides[2];
     p.B = (int)B; p.N = (int)N; p.H = (int)H; p.win_left = win_left; p.win_right = win_right; p.scale = scale;
+    SCONF_REQUIRE((rot_cos == nullptr) == (rot_sin == nullptr), "sconf_attn_bwd: rot_cos and rot_sin go together");
+    p.rot_cos = rot_cos; p.rot_sin = rot_sin;
     const long rows = B * N * H;
     set_lds_attrs();
     dim3 grid((unsigned)(cdiv(N, 128) * H * B)), block(256);

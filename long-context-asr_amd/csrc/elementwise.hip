@@ -45,7 +45,7 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* __rest
 }
 
 // All bf16 weight shadows of a model in ONE launch (the per-step refresh after the optimiser has moved the f32 masters).
-// table[e] = {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R, C, first 32x32-tile index of the entry}; entry n is a
+// table[e] = {src f32 (R,C), dst bf16 (R,C) or 0, dstT bf16 (C,R) or 0, R (negative: regroup, below), C, first 32x32-tile index}; entry n is a
 // sentinel holding the total tile count.  Block b finds its entry by binary search over the tile prefix.
 struct ShadowEntry { const float* src; bf16* dst; bf16* dstT; long R, C, tile0; };
 __global__ __launch_bounds__(256) void cast_shadows_kernel(const ShadowEntry* __restrict__ table, int n) {
@@ -54,7 +54,11 @@ __global__ __launch_bounds__(256) void cast_shadows_kernel(const ShadowEntry* __
     int lo = 0, hi = n;                                    // table[lo].tile0 <= b < table[hi].tile0
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (table[mid].tile0 <= b) lo = mid; else hi = mid; }
     const ShadowEntry e = table[lo];
-    const int R = (int)e.R, C = (int)e.C, tiles_c = (C + 31) >> 5;
+    // R < 0: the source rows are the reference's "(h d qkv)" interleave of the fused qkv projection (attention.py:485); the shadow is
+    // written with rows regrouped as [q | k | v] (row 3j + w -> w * R/3 + j), so that the GEMM's output columns are three
+    // contiguous (h, d) blocks and no de-interleave pass over the activations is needed.
+    const bool regroup = e.R < 0;
+    const int R = (int)(regroup ? -e.R : e.R), C = (int)e.C, tiles_c = (C + 31) >> 5, R3 = R / 3;
     const int t = (int)(b - e.tile0), r0 = (t / tiles_c) * 32, c0 = (t % tiles_c) * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;              // 32 x 8
 #pragma unroll
@@ -62,14 +66,39 @@ __global__ __launch_bounds__(256) void cast_shadows_kernel(const ShadowEntry* __
         const int r = r0 + ty + 8 * k, c = c0 + tx;
         const float v = (r < R && c < C) ? e.src[(long)r * C + c] : 0.f;
         tile[ty + 8 * k][tx] = v;
-        if (e.dst && r < R && c < C) e.dst[(long)r * C + c] = (bf16)v;
+        const int rd = regroup ? (r % 3) * R3 + r / 3 : r;
+        if (e.dst && r < R && c < C) e.dst[(long)rd * C + c] = (bf16)v;
     }
     if (!e.dstT) return;                                   // uniform per block
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int c = c0 + ty + 8 * k, r = r0 + tx;
-        if (c < C && r < R) e.dstT[(long)c * R + r] = (bf16)tile[tx][ty + 8 * k];
+        const int rd = regroup ? (r % 3) * R3 + r / 3 : r;
+        if (c < C && r < R) e.dstT[(long)c * R + rd] = (bf16)tile[tx][ty + 8 * k];
+    }
+}
+
+// NeoX rotary applied IN PLACE to the q and k blocks of a regrouped qkv activation (M, 3, H, D) bf16 (v untouched): one thread
+// rotates 8 pairs (d = i..i+7 and d + D/2) of one (row, q-or-k, head).  cos/sin: (N, D/2) f32 (rotary_emb.py:44-57, 61-73).
+__global__ void rotary_inplace_kernel(bf16* __restrict__ qkv, const float* __restrict__ cosT, const float* __restrict__ sinT,
+                                      long M, int N, int H, int D) {
+    const int half = D / 2, gpr = half / 8;
+    const long total = M * 2 * H * gpr;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int gi = (int)(idx % gpr);
+        const int h = (int)((idx / gpr) % H);
+        const int w = (int)((idx / ((long)gpr * H)) % 2);
+        const long m = idx / ((long)gpr * H * 2);
+        const int n = (int)(m % N), i0 = gi * 8;
+        bf16* p1 = qkv + ((m * 3 + w) * H + h) * D + i0;
+        bf16* p2 = p1 + half;
+        float c[8], s[8], a[8], b[8], o1[8], o2[8];
+        load8(cosT + (long)n * half + i0, c); load8(sinT + (long)n * half + i0, s);
+        load8(p1, a); load8(p2, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { o1[e] = a[e] * c[e] - b[e] * s[e]; o2[e] = b[e] * c[e] + a[e] * s[e]; }   // x*cos + rotate_half(x)*sin
+        store8(p1, o1); store8(p2, o2);
     }
 }
 
@@ -307,6 +336,19 @@ SCONF_API int sconf_cast_shadows(const void* table, int64_t n_entries, int64_t t
     if (n_entries == 0 || total_tiles == 0) return 0;
     hipLaunchKernelGGL(cast_shadows_kernel, dim3((unsigned)total_tiles), dim3(256), 0, stream, (const ShadowEntry*)table, (int)n_entries);
     SCONF_LAUNCH_OK("sconf_cast_shadows");
+    return 0;
+}
+
+// apply_rotary_pos_emb (rotary_emb.py:61-73, attention.py:498-507) in place on the q and k blocks of qkv (B*N, 3, H, D) bf16 - the
+// layout the qkv GEMM writes when its weight shadow is regrouped (sconf_cast_shadows, R < 0).
+SCONF_API int sconf_rotary_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t B, int64_t N, int64_t H, int64_t D,
+                                   hipStream_t stream) {
+    SCONF_REQUIRE(D % 16 == 0, "sconf_rotary_inplace: head_dim %ld must be a multiple of 16", (long)D);
+    const long M = B * N;
+    if (M == 0) return 0;
+    const long total = M * 2 * H * (D / 16);
+    hipLaunchKernelGGL(rotary_inplace_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, stream, (bf16*)qkv, cos_tab, sin_tab, M, (int)N, (int)H, (int)D);
+    SCONF_LAUNCH_OK("sconf_rotary_inplace");
     return 0;
 }
 

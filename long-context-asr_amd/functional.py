@@ -31,13 +31,14 @@ BF16, F32 = torch.bfloat16, torch.float32
 # tensor's version counter plus an epoch that the fused optimiser bumps (its kernel writes the parameters behind autograd's
 # back) - and `wcast` / `wcast_t` re-cast a shadow whose master has moved on: a shadow can never be older than its use.
 class _Shadow:
-    __slots__ = ('w', 'rows', 'cols', 'n', 't', 'vn', 'vt')
+    __slots__ = ('w', 'rows', 'cols', 'n', 't', 'vn', 'vt', 'regroup')
 
-    def __init__(self, w):
+    def __init__(self, w, regroup=False):
         self.w = w                                   # keeps the master alive and lets refresh re-read its data_ptr
         self.rows = w.shape[0]; self.cols = w.numel() // max(w.shape[0], 1)
         self.n = None; self.t = None
         self.vn = self.vt = None                     # (version, epoch) of the master at the last cast of n / t
+        self.regroup = regroup                       # rows "(h d qkv)" -> [q | k | v] (the fused qkv projection, attention.py:485)
 
 
 _shadows: dict = {}                                  # (data_ptr, shape) -> _Shadow
@@ -70,7 +71,7 @@ def refresh_weight_shadows() -> None:
     if key != _table['key']:
         rows, tile0 = [], 0
         for e, k in zip(ents, key):
-            rows.append([k[0], k[1], k[2], e.rows, e.cols, tile0])
+            rows.append([k[0], k[1], k[2], -e.rows if e.regroup else e.rows, e.cols, tile0])
             tile0 += ((e.rows + 31) // 32) * ((e.cols + 31) // 32)
         rows.append([0, 0, 0, 0, 0, tile0])
         _table.update(key=key, dev=torch.tensor(rows, dtype=torch.int64, device=ents[0].w.device), tiles=tile0)
@@ -81,38 +82,49 @@ def refresh_weight_shadows() -> None:
         if e.t is not None: e.vt = st
 
 
-def _shadow(w: torch.Tensor) -> _Shadow:
-    key = (w.data_ptr(), tuple(w.shape))
+def _shadow(w: torch.Tensor, regroup: bool = False) -> _Shadow:
+    key = (w.data_ptr(), tuple(w.shape), regroup)
     e = _shadows.get(key)
     if e is None:
         if w.dtype != F32:
             raise TypeError('master weights are float32')
-        e = _Shadow(w.detach())
+        if regroup and w.shape[0] % 3:
+            raise ValueError('a regrouped shadow needs 3 * H * D rows')
+        e = _Shadow(w.detach(), regroup)
         _shadows[key] = e
     return e
 
 
-def wcast(w: torch.Tensor) -> torch.Tensor:
-    """bf16 copy of an f32 master weight, viewed 2-D (out_features, in_features*k)."""
-    e = _shadow(w)
+def _regrouped(w2: torch.Tensor) -> torch.Tensor:
+    """rows (j, which) -> (which, j): "(h d qkv)" -> [q | k | v] (what sconf_cast_shadows does for a regroup entry)."""
+    R, C = w2.shape
+    return w2.view(R // 3, 3, C).permute(1, 0, 2).reshape(R, C)
+
+
+def wcast(w: torch.Tensor, regroup: bool = False) -> torch.Tensor:
+    """bf16 copy of an f32 master weight, viewed 2-D (out_features, in_features*k).  regroup: the fused qkv projection's rows
+    "(h d qkv)" come out as [q | k | v], so its GEMM writes three contiguous (h, d) blocks per token."""
+    e = _shadow(w, regroup)
     st = _state(e)
-    if e.n is None:                                  # first use: cast now, refreshed in bulk from the next forward on
-        e.n = ops.cast(w.detach().reshape(e.rows, e.cols), BF16)
-    elif e.vn != st:                                 # the master changed since the last cast (module-level use after an update)
-        e.n.copy_(ops.cast(w.detach().reshape(e.rows, e.cols), BF16))
+    if e.n is None or e.vn != st:                    # first use / the master changed since the last cast (module-level use after an update)
+        src = w.detach().reshape(e.rows, e.cols)
+        fresh = ops.cast(_regrouped(src).contiguous() if regroup else src, BF16)
+        if e.n is None: e.n = fresh                  # refreshed in bulk from the next forward on
+        else: e.n.copy_(fresh)
     e.vn = st
     return e.n
 
 
-def wcast_t(w: torch.Tensor) -> torch.Tensor:
+def wcast_t(w: torch.Tensor, regroup: bool = False) -> torch.Tensor:
     """Transposed bf16 copy (in_features*k, out_features) of an f32 master weight: dgrad dx = dy W becomes the NT GEMM
     dy (W^T)^T whose B operand is K-contiguous (wide epilogue, no transposed LDS reads).  Weights are a few MB."""
-    e = _shadow(w)
+    e = _shadow(w, regroup)
     st = _state(e)
-    if e.t is None:
-        e.t = ops.cast_transpose(w.detach().reshape(e.rows, e.cols).contiguous())
-    elif e.vt != st:
-        e.t.copy_(ops.cast_transpose(w.detach().reshape(e.rows, e.cols).contiguous()))
+    if e.t is None or e.vt != st:
+        src = w.detach().reshape(e.rows, e.cols)
+        fresh = ops.cast_transpose((_regrouped(src) if regroup else src).contiguous())
+        if e.t is None: e.t = fresh
+        else: e.t.copy_(fresh)
     e.vt = st
     return e.t
 
@@ -309,6 +321,12 @@ def ff_block(x, nw, nb, w1, w2, b1, b2, scale=0.5, mode='layer_norm', eps=1e-5, 
 # x + out_proj(Attention(rotary(qkv(norm(x)))))  — PreNorm(Attention); attention.py:509-551
 # =================================================================================================
 class AttnBlockFn(Function):
+    """The qkv projection reads a REGROUPED bf16 shadow of its weight (rows [q | k | v] instead of the reference's "(h d qkv)"
+    interleave), so its GEMM writes (M, 3, H, D) and q, k, v are strided views of that one buffer: no de-interleave pass.
+    Rotary is applied in place to the q and k blocks (forward) and, transposed, inside the attention backward's dQ / dK
+    epilogues, which write straight into one (M, 3, H, D) gradient buffer = the operand of the qkv dgrad / wgrad GEMMs.  Only the
+    (few MB) weight gradient is brought back to the reference's row order."""
+
     @staticmethod
     def forward(ctx, x, nw, nb, wqkv, wout, bqkv, bout, cos, sin, lengths, B: int, N: int, H: int, D: int, window,
                 mode: str, eps: float, residual: bool):
@@ -317,12 +335,15 @@ class AttnBlockFn(Function):
         if lengths is not None:
             if h is x: h = h.clone()
             ops.mask_rows_(h, lengths, B, N)                                          # attention.py:511
-        wqh, woh = wcast(wqkv), wcast(wout)
-        qkv = ops.gemm(h, wqh, 'nt', bias=bqkv)                                       # (M, H*D*3), "(h d qkv)" columns
-        q, k, v = ops.rotary_qkv_fwd(qkv, cos, sin, B, N, H, D)
-        o, lse = ops.attn_fwd(q, k, v, lengths, window)                               # padded query rows come back zero
+        wqh, woh = wcast(wqkv, regroup=True), wcast(wout)
+        bq = None if bqkv is None else _regrouped(bqkv.detach().view(-1, 1)).view(-1).contiguous()
+        qkv = ops.gemm(h, wqh, 'nt', bias=bq)                                         # (M, 3*H*D) = (B, N, 3, H, D)
+        if cos is not None:
+            ops.rotary_inplace_(qkv, cos, sin, B, N, H, D)
+        q5 = qkv.view(B, N, 3, H, D)
+        o, lse = ops.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], lengths, window)  # padded query rows come back zero
         y = ops.gemm(o.view(B * N, H * D), woh, 'nt', bias=bout, resid=x if residual else None, out_dtype=F32)
-        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wqkv), wcast_t(wout), bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse)
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wqkv, regroup=True), wcast_t(wout), bqkv, bout, cos, sin, lengths, h, qkv, o, lse)
         ctx.cfg = (B, N, H, D, window, mode, eps, residual)
         ctx.P = (nw, nb, wqkv, wout, bqkv, bout)
         return y
@@ -331,17 +352,33 @@ class AttnBlockFn(Function):
     def backward(ctx, dy):
         B, N, H, D, window, mode, eps, residual = ctx.cfg
         pnw, pnb, pwq, pwo, pbq, pbo = ctx.P
-        x, nw, nb, mean, rstd, wqt, wot, bqkv, bout, cos, sin, lengths, h, q, k, v, o, lse = ctx.saved_tensors
+        x, nw, nb, mean, rstd, wqt, wot, bqkv, bout, cos, sin, lengths, h, qkv, o, lse = ctx.saved_tensors
         dy = dy.contiguous()
         dy16, dycs = _take_twin(dy)
         o2 = o.view(B * N, H * D)
         do = ops.gemm(dy16, wot, 'nt')                                                # (M, H*D)
         dwo = _wgrad(dy16, o2, pwo)
         dbo = _bgrad(dy16, pbo, colsum=dycs)
-        dq, dk, dv = ops.attn_bwd(q, k, v, o, do.view(B, N, H, D), lse, lengths, window)
-        dqkv = ops.rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D)
-        dwq = _wgrad(dqkv, h, pwq)
-        dbq = _bgrad(dqkv, pbq)
+        q5 = qkv.view(B, N, 3, H, D)
+        dqkv = torch.empty_like(qkv)
+        d5 = dqkv.view(B, N, 3, H, D)
+        ops.attn_bwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], o, do.view(B, N, H, D), lse, lengths, window,
+                     rot=None if cos is None else (cos, sin), out=(d5[:, :, 0], d5[:, :, 1], d5[:, :, 2]))
+        # weight / bias gradients come out in the regrouped row order: bring the (3HD, d) result back to "(h d qkv)"
+        Mtok, HD3 = dqkv.shape
+        sk = ops.pick_split_k(HD3, h.shape[1], Mtok)
+        gq = ops.gemm(dqkv, h, 'tn', out_dtype=F32, split_k=sk)                       # rows [q | k | v]
+        gq = gq.view(3, HD3 // 3, -1).permute(1, 0, 2)                                # -> (h d) x qkv x in_features (a view)
+        gw = _G(pwq, (HD3 // 3, 3, h.shape[1]))
+        if gw.direct: gw.t.add_(gq)
+        dwq = gw.out() if gw.direct else gq.reshape(pwq.shape)
+        dbq = None
+        if pbq is not None:
+            gb = _G(pbq, (HD3 // 3, 3))
+            cs = torch.zeros(HD3, dtype=F32, device=dqkv.device)
+            ops.colsum_(dqkv, cs)
+            if gb.direct: gb.t.add_(cs.view(3, HD3 // 3).t())
+            dbq = gb.out() if gb.direct else cs.view(3, HD3 // 3).t().reshape(pbq.shape)
         dh = ops.gemm(dqkv, wqt, 'nt')
         if lengths is not None:
             ops.mask_rows_(dh, lengths, B, N)

@@ -29,7 +29,8 @@ PROTOTYPES = {
     'sconf_colsum': [vp, i32, vp, i64, i64, i64, f32, vp],
     'sconf_mask_rows': [vp, i32, vp, i64, i64, i64, vp],
     'sconf_attn_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, i32, i32, f32, vp],
-    'sconf_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp],
+    'sconf_attn_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, f32, vp, vp, vp],
+    'sconf_rotary_inplace': [vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_glu_dwconv_fwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_brn_finalize': [vp, i64, vp, vp, vp, vp, vp, vp, i64, i32, f32, f32, vp],
     'sconf_affine_silu_fwd': [vp, vp, vp, i64, i64, vp],

@@ -221,6 +221,14 @@ def rotary_qkv_bwd(dq: torch.Tensor, dk: torch.Tensor, dv: torch.Tensor, cos, si
     return dqkv
 
 
+def rotary_inplace_(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, B: int, N: int, H: int, D: int) -> torch.Tensor:
+    """NeoX rotary on the q and k blocks of a regrouped qkv activation (B*N, 3*H*D) = (B,N,3,H,D) bf16, in place."""
+    _chk(qkv, 'qkv', torch.bfloat16); _chk(cos, 'cos', torch.float32); _chk(sin, 'sin', torch.float32)
+    if qkv.numel() != B * N * 3 * H * D or tuple(cos.shape) != (N, D // 2): raise ValueError('rotary_inplace_: shape mismatch')
+    _lib.call('sconf_rotary_inplace', _p(qkv), _p(cos), _p(sin), B, N, H, D, _stream())
+    return qkv
+
+
 def softmax_fwd(x: torch.Tensor, log: bool, out_dtype: torch.dtype) -> torch.Tensor:
     _chk(x, 'x')
     Cn = x.shape[-1]; M = x.numel() // Cn
@@ -283,15 +291,24 @@ def attn_fwd(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lengths: Optiona
     return o, lse
 
 
-def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale: Optional[float] = None):
+def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale: Optional[float] = None, rot=None, out=None):
+    """-> (dq, dk, dv) bf16 (B,N,H,D).  out: three (B,N,H,D) bf16 views to write into (e.g. the blocks of one (B,N,3,H,D) buffer).
+    rot = (cos, sin) f32 (N, D/2): q and k are rotary-rotated; dq and dk come back as gradients of the unrotated q, k."""
     B, N, H, D = q.shape
-    dq = torch.empty(B, N, H, D, dtype=torch.bfloat16, device=q.device)
-    dk = torch.empty_like(dq); dv = torch.empty_like(dq)
+    if out is None:
+        dq = torch.empty(B, N, H, D, dtype=torch.bfloat16, device=q.device)
+        dk = torch.empty_like(dq); dv = torch.empty_like(dq)
+    else:
+        dq, dk, dv = out
     delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
     sc = float(scale) if scale is not None else D ** -0.5
+    cos, sin = rot if rot is not None else (None, None)
+    if cos is not None:
+        _chk(cos, 'cos', torch.float32); _chk(sin, 'sin', torch.float32)
+        if tuple(cos.shape) != (N, D // 2): raise ValueError('rotary tables must be (N, D/2)')
     _lib.call('sconf_attn_bwd', _p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(lengths),
               B, N, H, D, _strides3(q), _strides3(k), _strides3(v), _strides3(o), _strides3(dout), _strides3(dq), _strides3(dk),
-              _strides3(dv), int(window[0]), int(window[1]), sc, _stream())
+              _strides3(dv), int(window[0]), int(window[1]), sc, _p(cos), _p(sin), _stream())
     return dq, dk, dv
 
 

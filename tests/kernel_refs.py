@@ -115,7 +115,10 @@ def cast_shadows(table, n_entries, total_tiles):
     """Reference of sconf_cast_shadows: the table holds RAW addresses (here: of CPU tensors), exactly like the C ABI."""
     import ctypes
     for src, dst, dst_t, R, C, _ in table[:n_entries].tolist():
+        regroup = R < 0                                       # "(h d qkv)" rows -> [q | k | v] (sconf.h)
+        R = abs(R)
         w = torch.frombuffer((ctypes.c_float * (R * C)).from_address(src), dtype=torch.float32).view(R, C)
+        if regroup: w = w.view(R // 3, 3, C).permute(1, 0, 2).reshape(R, C)
         if dst:
             torch.frombuffer((ctypes.c_uint16 * (R * C)).from_address(dst), dtype=torch.bfloat16).view(R, C).copy_(w)
         if dst_t:
@@ -142,6 +145,13 @@ def rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D):
     dq, dk, dv = dq.to(f32), dk.to(f32), dv.to(f32)
     if cos is not None: dq, dk = _rot(dq, cos, sin, -1.0), _rot(dk, cos, sin, -1.0)
     return torch.stack([dq, dk, dv], dim=-1).reshape(B * N, H * D * 3).to(torch.bfloat16)
+
+
+def rotary_inplace_(qkv, cos, sin, B, N, H, D):
+    t = qkv.view(B, N, 3, H, D)
+    t[:, :, 0] = _rot(t[:, :, 0].to(f32), cos, sin).to(qkv.dtype)
+    t[:, :, 1] = _rot(t[:, :, 1].to(f32), cos, sin).to(qkv.dtype)
+    return qkv
 
 
 def softmax_fwd(x, log, out_dtype):
@@ -197,7 +207,7 @@ def attn_fwd(q, k, v, lengths, window=(-1, -1), scale=None):
     return o.contiguous().to(torch.bfloat16), lse.contiguous()
 
 
-def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale=None):
+def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale=None, rot=None, out=None):
     B, N, H, D = q.shape
     sc = scale if scale is not None else D ** -0.5
     qf, kf, vf = (t.to(f32).detach().clone().requires_grad_(True) for t in (q, k, v))
@@ -215,7 +225,13 @@ def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale=None):
             oo = oo.masked_fill(qpad[:, :, None, None], 0.0)
         oo.backward(g)
     bf = torch.bfloat16
-    return qf.grad.contiguous().to(bf), kf.grad.contiguous().to(bf), vf.grad.contiguous().to(bf)
+    dq, dk, dv = qf.grad, kf.grad, vf.grad
+    if rot is not None:                                     # gradients of the unrotated q, k: transpose of the rotation
+        dq, dk = _rot(dq, rot[0], rot[1], -1.0), _rot(dk, rot[0], rot[1], -1.0)
+    if out is not None:
+        out[0].copy_(dq.to(bf)); out[1].copy_(dk.to(bf)); out[2].copy_(dv.to(bf))
+        return out
+    return dq.contiguous().to(bf), dk.contiguous().to(bf), dv.contiguous().to(bf)
 
 
 def _glu_masked(g, lengths, B, N):

@@ -240,6 +240,49 @@ def test_rotary_qkv(ops, H, D):
         close(d, R.rotary_qkv_bwd(qr, kr, vr, c, s, B, N, H, D), name='rot bwd')
 
 
+@pytest.mark.parametrize('H,D,N', [(2, 32, 150), (6, 128, 300)])
+def test_fused_qkv_path_regrouped_shadow_inplace_rotary_and_rotary_transpose_in_attention_backward(ops, H, D, N):
+    """Round 2: the qkv weight shadow is written regrouped ("(h d qkv)" rows -> [q | k | v]), the GEMM output (M, 3, H, D) is rotated
+    in place and the attention backward returns dq, dk with the transpose of the rotation applied, into the blocks of ONE
+    (M, 3, H, D) buffer.  Each piece against its reference, and the whole against the round-1 path (de-interleave + rotary pass,
+    attention, transpose pass)."""
+    import sys
+    sys.path.insert(0, '.')
+    from oracle.sconformer_ref import rotary_tables
+    B = 2
+    cos, sin = rotary_tables(N, D, 1.5e6)
+    cos, sin = cos[:, :D // 2].contiguous(), sin[:, :D // 2].contiguous()
+    # (1) regrouped shadows through sconf_cast_shadows (negative R), row-major and transposed
+    w = rnd(3 * H * D, 96, dtype=F32)
+    wd = dev(w)
+    dn, dt = torch.zeros(3 * H * D, 96, dtype=BF, device='cuda'), torch.zeros(96, 3 * H * D, dtype=BF, device='cuda')
+    tiles = ((3 * H * D + 31) // 32) * 3
+    tab = torch.tensor([[wd.data_ptr(), dn.data_ptr(), dt.data_ptr(), -3 * H * D, 96, 0], [0, 0, 0, 0, 0, tiles]], dtype=torch.int64, device='cuda')
+    ops.cast_shadows(tab, 1, tiles)
+    want = w.view(H * D, 3, 96).permute(1, 0, 2).reshape(3 * H * D, 96).to(BF)
+    assert torch.equal(dn.cpu(), want) and torch.equal(dt.cpu(), want.t().contiguous())
+    # (2) in-place rotary on the q, k blocks of (M, 3, H, D); v untouched
+    qkv_i = rnd(B * N, H * D * 3)                                       # reference layout "(h d qkv)"
+    qkv_g = qkv_i.view(B * N, H * D, 3).permute(0, 2, 1).reshape(B * N, 3 * H * D).contiguous()     # regrouped [q | k | v]
+    got = ops.rotary_inplace_(dev(qkv_g).clone(), dev(cos), dev(sin), B, N, H, D).view(B, N, 3, H, D)
+    qr, kr, vr = R.rotary_qkv_fwd(qkv_i, cos, sin, B, N, H, D)
+    close(got[:, :, 0], qr, name='in-place rot q'); close(got[:, :, 1], kr, name='in-place rot k')
+    assert torch.equal(got[:, :, 2].cpu(), vr)
+    # (3) attention backward with the rotation's transpose in its epilogues, written into one buffer
+    q, k, v = got[:, :, 0], got[:, :, 1], got[:, :, 2]                 # strided views
+    lens = dev(torch.tensor([N, N - 37], dtype=torch.int32))
+    o, lse = ops.attn_fwd(q, k, v, lens)
+    do = dev(rnd(B, N, H, D, seed=9))
+    dqkv = torch.zeros(B, N, 3, H, D, dtype=BF, device='cuda')
+    ops.attn_bwd(q, k, v, o, do, lse, lens, rot=(dev(cos), dev(sin)), out=(dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]))
+    dq0, dk0, dv0 = ops.attn_bwd(q, k, v, o, do, lse, lens)            # round-1 path: plain gradients, then the transpose pass
+    old = ops.rotary_qkv_bwd(dq0, dk0, dv0, dev(cos), dev(sin), B, N, H, D).view(B * N, H * D, 3).permute(0, 2, 1).reshape(B, N, 3, H, D)
+    close(dqkv, old.float().cpu(), name='dqkv fused vs two-pass', tol=1.2e-2)
+    assert torch.equal(dqkv[:, :, 2], dv0)
+    dqr, dkr, dvr = R.attn_bwd(q.float().cpu(), k.float().cpu(), v.float().cpu(), o.float().cpu(), do.float().cpu(), lse.cpu(), lens.cpu(), rot=(cos, sin))
+    close(dqkv[:, :, 0], dqr, name='dq rot^T', tol=2e-2); close(dqkv[:, :, 1], dkr, name='dk rot^T', tol=2e-2)
+
+
 @pytest.mark.parametrize('C', [128, 4096])
 def test_softmax(ops, C):
     M = 37
