@@ -132,10 +132,10 @@ class GemmTimer:
         # correction, see the file's header); the operand / output bytes of the same launches are computed here
         traffic, src = None, None
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r01_hbm_traffic_v12.json')))
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic.json')))
             key = GEMM_KERNELS.get(top, '').split(' (')[0]
             if key in tj['kernels']:
-                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r01_hbm_traffic_v12.json (PMC, same batch)'
+                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r02_hbm_traffic.json (PMC, same batch)'
         except Exception:
             pass
         return dict(bound='mfma', kernel=GEMM_KERNELS.get(top, str(top)), achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,

@@ -414,8 +414,10 @@ def test_convmod_fwd_bwd(ops, B, N, d, lens):
 
 
 # ------------------------------------------------------------------------------------------------ subsampler
-@pytest.mark.parametrize('B,T,C', [(2, 64, 32), (1, 203, 256)])
+@pytest.mark.parametrize('B,T,C', [(2, 64, 32), (1, 203, 256), (1, 131, 512), (2, 77, 96)])
 def test_subsample_ops(ops, B, T, C):
+    """C = 512: two channel blocks per wave in the MFMA stage 0->1 kernels (BASELINE config 5); C = 96: three of the eight waves own a
+    block; C = 32: one.  Odd T: ragged last conv rows."""
     F = 80
     x = rnd(B, F, T, dtype=F32)
     w0, b0 = rnd(C, 9, dtype=F32, seed=1) * 0.3, rnd(C, dtype=F32, seed=2) * 0.1
@@ -447,6 +449,19 @@ def test_subsample_ops(ops, B, T, C):
     R.sub_stage01_bwd_(dout, x, w0, b0, wd, *gs_)
     for a_, b_, nm in zip(gg_, gs_, ('dw0', 'db0', 'dwd', 'dbd')):
         close(a_, b_, name='stage01 ' + nm, tol=5e-3)
+    # the same through the VALU kernels (SCONF_SUB_MFMA=0: the path shapes outside the MFMA kernels' reach take) and with a bf16 mel
+    import os
+    os.environ['SCONF_SUB_MFMA'] = '0'
+    try:
+        close(ops.sub_stage01_fwd(dev(x), dev(w0), dev(b0), dev(wd), dev(bd)), d1fr, name='stage01 fwd (VALU kernels)')
+        gv_ = [torch.zeros_like(t_) for t_ in gg_]
+        ops.sub_stage01_bwd_(dev(dout), dev(x), dev(w0), dev(b0), dev(wd), *gv_)
+        for a_, b_, nm in zip(gv_, gs_, ('dw0', 'db0', 'dwd', 'dbd')):
+            close(a_, b_, name='stage01 (VALU kernels) ' + nm, tol=5e-3)
+    finally:
+        del os.environ['SCONF_SUB_MFMA']
+    xb = x.to(BF)
+    close(ops.sub_stage01_fwd(dev(xb), dev(w0), dev(b0), dev(wd), dev(bd)), R.sub_stage01_fwd(xb.float(), w0, b0, wd, bd), name='stage01 fwd, bf16 mel')
     pre2 = rnd(B * 7, 10, C, seed=6)
     s = ops.sub_silu_transpose(dev(pre2))
     sr = R.sub_silu_transpose(pre2)

@@ -3,6 +3,9 @@ Usage: python tools/pmc_summary.py out.json dir1 [dir2 ...]   (one directory per
 import csv, glob, json, os, re, sys
 
 def short(name):
+    if name.startswith('_ZN'):                                  # still mangled: keep the kernel's own identifier + template digits
+        m = re.search(r'N_1\d+([A-Za-z_0-9]*?_kernel)(I\S*?E)?Ev', name)
+        if m: return (m.group(1) + (m.group(2) or ''))[:80]
     name = re.sub(r'\(anonymous namespace\)::', '', name)
     name = re.sub(r'^void ', '', name)
     return name.split('(')[0][:80]
