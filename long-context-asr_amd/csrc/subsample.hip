@@ -538,6 +538,7 @@ __global__ __launch_bounds__(256) void stage01_bwd_kernel(const TX* __restrict__
 // subsample_mfma.hip: conv0 on the matrix cores; return 1 when they took the problem
 int sconf_stage01_fwd_mfma(const void* x, int x_dtype, const float* w0, const float* b0, const float* wd, const float* bd, void* d1,
                            int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream);
+int sconf_dwconv_window_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int64_t Ti, int64_t Fi, int64_t C, hipStream_t stream);
 int sconf_stage01_bwd_mfma(const void* dd1, const void* x, int x_dtype, const float* w0, const float* b0, const float* wd,
                            float* dw0, float* db0, float* dwd, float* dbd, int64_t B, int64_t F, int64_t T, int64_t C, hipStream_t stream);
 namespace {
@@ -580,6 +581,7 @@ SCONF_API int sconf_sub_dwconv_fwd(const void* x, const float* w, const float* b
     SUB_REQ("sconf_sub_dwconv_fwd");
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
     if (B * To * Fo == 0) return 0;
+    if (sconf_dwconv_window_fwd(x, w, bias, y, B, Ti, Fi, C, stream)) { SCONF_LAUNCH_OK("sconf_sub_dwconv_fwd"); return 0; }
     const LaunchGeo g = geo_for(C, B, (long)To * Fo, 16384);
     hipLaunchKernelGGL(dwconv2d_fwd_kernel, g.grid, dim3(g.threads), 0, stream, (const bf16*)x, w, bias, (bf16*)y, (int)Ti, (int)Fi, (int)C, To, Fo, g.PL, g.iters);
     SCONF_LAUNCH_OK("sconf_sub_dwconv_fwd");

@@ -176,6 +176,103 @@ __global__ __launch_bounds__(512, 4) void stage01_fwd_mfma_kernel(const TX* __re
 }
 
 // ================================================================================================================
+// The later depthwise stage (conv[5]): y[to][fo][c] = bias[c] + sum_ij w[c][i][j] * SiLU(x[2to+i-1][2fo+j-1][c]) on a channels-last bf16
+// pre-activation tensor x (B,Ti,Fi,C).  Same structure as the fused stage above minus conv0: an input row is read ONCE, its SiLU
+// taken ONCE (the position-centric kernel of subsample.hip recomputes it for each of the 2.25 outputs an element feeds: 500 VALU
+// instructions per 8 outputs) into the 3-row LDS window of bf16 pairs, and the taps are v_dot2c_f32_bf16.
+// grid (ceil(To / rows_per_block), B), 512 threads; needs C % 32 == 0, C <= 512.
+// ================================================================================================================
+template <int NCB>
+__global__ __launch_bounds__(512, 4) void dwconv_window_fwd_kernel(const bf16* __restrict__ x, const float* __restrict__ wdg, const float* __restrict__ bdg,
+                                                                   bf16* __restrict__ y, int Ti, int Fi, int C, int To, int Fo, int rows_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int NPAIR = Fi / 2 + 2, QS = 4 * C + 128, SLOT = NPAIR * QS;
+    char* act = smem;                                    // [3][NPAIR][QS]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = blockIdx.y, ncb = C / 32;
+    const bf16* xb = x + (long)b * Ti * Fi * C;
+    unsigned wj0[NCB][3][2], wj12[NCB][3][2];
+    float bd2[NCB][2];
+    const int cp = lane & 15, fg = lane >> 4;
+#pragma unroll
+    for (int u = 0; u < NCB; ++u) {
+        const int cb = min(wave + 8 * u, ncb - 1);
+#pragma unroll
+        for (int ch = 0; ch < 2; ++ch) {
+            const int c = cb * 32 + 2 * cp + ch;
+            bd2[u][ch] = bdg[c];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { wj0[u][i][ch] = pack2(0.f, wdg[c * 9 + 3 * i]); wj12[u][i][ch] = pack2(wdg[c * 9 + 3 * i + 1], wdg[c * 9 + 3 * i + 2]); }
+        }
+    }
+    for (int i = tid; i < 3 * (QS / 4); i += 512) *reinterpret_cast<unsigned*>(act + (i / (QS / 4)) * SLOT + (i % (QS / 4)) * 4) = 0u;
+
+    // producer: item = (pair q' of adjacent input bins (2q', 2q'+1), group of 8 channels): 2 x 16 B in, 8 SiLU pairs (32 B) out
+    const int npq = (Fi + 1) / 2, items = npq * (C / 8);
+    struct Row { bf16x8 a[2], b[2]; };
+    auto fetch = [&](Row& r, int ti) {
+        const bool row_ok = ti >= 0 && ti < Ti;
+        const bf16* src = xb + (long)min(max(ti, 0), Ti - 1) * Fi * C;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = min(tid + 512 * it, items - 1), q = idx / (C / 8), c8 = idx - q * (C / 8);
+            const bf16x8 va = *reinterpret_cast<const bf16x8*>(src + (long)(2 * q) * C + c8 * 8);
+            const bf16x8 vb = *reinterpret_cast<const bf16x8*>(src + (long)min(2 * q + 1, Fi - 1) * C + c8 * 8);
+            r.a[it] = row_ok ? va : z;                       // SiLU(0) = 0: rows / bins outside the tensor are the zero padding
+            r.b[it] = (row_ok && 2 * q + 1 < Fi) ? vb : z;
+        }
+    };
+    auto produce = [&](const Row& r, int ti) {
+        char* arow = act + ((ti + 3) % 3) * SLOT;
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int idx = tid + 512 * it;
+            if (idx < items) {
+                const int q = idx / (C / 8), c8 = idx - q * (C / 8);
+                unsigned w[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) w[e] = pack2(siluf_((float)r.a[it][e]), siluf_((float)r.b[it][e]));
+                uint4* d = reinterpret_cast<uint4*>(arow + (q + 1) * QS + c8 * 32);     // window pair index = (f + 2) >> 1 = q + 1
+                d[0] = make_uint4(w[0], w[1], w[2], w[3]); d[1] = make_uint4(w[4], w[5], w[6], w[7]);
+            }
+        }
+    };
+
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(To, r0 + rows_per_block);
+    const int ti_first = 2 * r0 - 1, ti_last = 2 * (r1 - 1) + 1;
+    Row row;
+    fetch(row, ti_first);
+    __syncthreads();                                         // the zero pairs
+    for (int ti = ti_first; ti <= ti_last; ++ti) {
+        produce(row, ti);
+        if (ti < ti_last) fetch(row, ti + 1);               // in flight during the depthwise phase / the barrier
+        __syncthreads();                                     // row ti of the window complete
+        if ((ti & 1) == 0) continue;
+        const int to = (ti - 1) >> 1;
+        if (to < r0) continue;
+#pragma unroll
+        for (int u = 0; u < NCB; ++u) {
+            if (wave + 8 * u >= ncb) break;
+            const int c0 = (wave + 8 * u) * 32 + 2 * cp;
+            for (int fo = fg; fo < Fo; fo += 4) {
+                float a0 = bd2[u][0], a1 = bd2[u][1];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    const char* srow = act + ((2 * to + i - 1 + 3) % 3) * SLOT + c0 * 4;
+                    const uint2 pa = *reinterpret_cast<const uint2*>(srow + fo * QS);
+                    const uint2 pb = *reinterpret_cast<const uint2*>(srow + (fo + 1) * QS);
+                    a0 = dot2(pa.x, wj0[u][i][0], a0); a0 = dot2(pb.x, wj12[u][i][0], a0);
+                    a1 = dot2(pa.y, wj0[u][i][1], a1); a1 = dot2(pb.y, wj12[u][i][1], a1);
+                }
+                *reinterpret_cast<unsigned*>(y + (((long)b * To + to) * Fo + fo) * C + c0) = pack2(a0, a1);
+            }
+        }
+        __syncthreads();                                     // the slot of row 2 to - 1 is overwritten by row 2 to + 2
+    }
+}
+
+// ================================================================================================================
 // backward: parameter gradients of conv0 (dw0, db0) and of the first depthwise conv (dwd, dbd) from dd1 (B,T4,F4,C), one pass over
 // the conv0 positions.  grid (ceil(T2 / rows_per_block), B), 512 threads, rows_per_block even; wave w owns channel blocks w, w+8.
 // Per conv0 row t2 and channel block:   pre = patch . W0^T (MFMA)  ->  sg = sigmoid(pre), s = pre sg
@@ -375,5 +472,24 @@ int sconf_stage01_bwd_mfma(const void* dd1, const void* x, int x_dtype, const fl
     if (x_dtype == SCONF_F32) { if (C <= 256) LB(float, 1); else LB(float, 2); }
     else                      { if (C <= 256) LB(bf16, 1); else LB(bf16, 2); }
 #undef LB
+    return 1;
+}
+
+int sconf_dwconv_window_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int64_t Ti, int64_t Fi, int64_t C, hipStream_t stream) {
+    const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
+    if (C % 32 != 0 || C > 512 || ((Fi + 1) / 2) * (C / 8) > 1024) return 0;
+    if (const char* e = getenv("SCONF_SUB_MFMA")) if (e[0] == '0') return 0;                   // A/B switch (shared with the fused stage)
+    const size_t sh = 3 * (size_t)(Fi / 2 + 2) * (4 * C + 128);
+    if (sh > 160 * 1024) return 0;
+    long target = 4096;
+    if (const char* e = getenv("SCONF_SUB_FWD_BLOCKS")) target = atol(e);
+    const int rpb = std::max(1, (int)cdiv((long)To * B, target));
+    dim3 grid(cdiv(To, rpb), (unsigned)B), block(512);
+#define LW(NCB_) do { \
+        static bool attr = false; \
+        if (!attr) { (void)hipFuncSetAttribute((const void*)dwconv_window_fwd_kernel<NCB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+        hipLaunchKernelGGL((dwconv_window_fwd_kernel<NCB_>), grid, block, sh, stream, (const bf16*)x, w, bias, (bf16*)y, (int)Ti, (int)Fi, (int)C, To, Fo, rpb); } while (0)
+    if (C <= 256) LW(1); else LW(2);
+#undef LW
     return 1;
 }
