@@ -23,21 +23,34 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     return m + __logf(1.f + __expf(md - m) + __expf(mn - m));
 }
 
-__global__ void ctc_gather_kernel(const float* __restrict__ lp, const int* __restrict__ targets, const int* __restrict__ in_len,
-                                  const int* __restrict__ tg_len, float* __restrict__ lpg, int B, int N, int C, int Smax,
-                                  int Lmax, int blank) {
-    const long total = (long)B * N * Lmax;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int s = (int)(idx % Lmax);
-        const long bt = idx / Lmax;
+// One workgroup per (sample, frame): the frame's whole log-prob row is streamed into LDS with 16-byte loads and the 2S+1 lattice
+// emissions are gathered from there (a thread-per-emission gather from global memory touched every 64-byte sector of the row
+// for 4 useful bytes each: 1.68 ms at B = 128, N = 2048, C = 4096 against 0.9 ms for row + lattice bytes at the HBM rate).
+__global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ lp, const int* __restrict__ targets, const int* __restrict__ in_len,
+                                                         const int* __restrict__ tg_len, float* __restrict__ lpg, int B, int N, int C, int Smax,
+                                                         int Lmax, int blank) {
+    extern __shared__ float row[];                      // [C]
+    for (long bt = blockIdx.x; bt < (long)B * N; bt += gridDim.x) {
         const int t = (int)(bt % N), b = (int)(bt / N);
-        float v = 0.f;
-        if (t < in_len[b] && s < 2 * tg_len[b] + 1 && s < Lmax) {
-            int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
-            lab = min(max(lab, 0), C - 1);               // an out-of-range label poisons the sample (alpha/beta kernel); never index with it
-            v = lp[bt * C + lab];
+        float* out = lpg + bt * Lmax;
+        const int L = 2 * tg_len[b] + 1;
+        if (t >= in_len[b]) {                           // frames past the sample's length: zeros (never read by the lattice)
+            for (int s = threadIdx.x; s < Lmax; s += 256) out[s] = 0.f;
+            continue;
         }
-        lpg[idx] = v;
+        __syncthreads();                                // the previous row's gathers are done
+        const float* src = lp + bt * C;
+        for (int c = threadIdx.x * 4; c < C; c += 1024) *reinterpret_cast<float4*>(row + c) = *reinterpret_cast<const float4*>(src + c);
+        __syncthreads();
+        for (int s = threadIdx.x; s < Lmax; s += 256) {
+            float v = 0.f;
+            if (s < L) {
+                int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
+                lab = min(max(lab, 0), C - 1);          // an out-of-range label poisons the sample (alpha/beta kernel); never index with it
+                v = row[lab];
+            }
+            out[s] = v;
+        }
     }
 }
 
@@ -183,7 +196,8 @@ SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, cons
     SCONF_REQUIRE(blank >= 0 && blank < C, "sconf_ctc_fwd: blank %d out of range", blank);
     SCONF_REQUIRE((long)(Lmax + 2) * 8 <= 160 * 1024, "sconf_ctc_fwd: lattice of %d states does not fit LDS", Lmax);
     const long total = B * N * Lmax;
-    hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)std::min<long>(cdiv(total, 256), 16384)), dim3(256), 0, stream,
+    SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "sconf_ctc_fwd: C must be a multiple of 4 and one row must fit LDS (%ld classes)", (long)C);
+    hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)std::min<long>(B * N, 65536)), dim3(256), (size_t)C * 4, stream,
                        log_probs, targets, input_lengths, target_lengths, lpg, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning

@@ -86,7 +86,7 @@ __device__ __forceinline__ bf16x8 w0_frag(const float* __restrict__ w0g, const f
 // 16-lane groups of the depthwise read over all banks).
 // ================================================================================================================
 template <typename TX, int NCB>      // NCB = channel blocks per wave (1: C <= 256, 2: C <= 512)
-__global__ __launch_bounds__(512, 4) void stage01_fwd_mfma_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
+__global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_fwd_mfma_kernel(const TX* __restrict__ x, const float* __restrict__ w0g, const float* __restrict__ b0g,
                                                                   const float* __restrict__ wdg, const float* __restrict__ bdg, bf16* __restrict__ d1,
                                                                   int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -120,14 +120,16 @@ __global__ __launch_bounds__(512, 4) void stage01_fwd_mfma_kernel(const TX* __re
 
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T4, r0 + rows_per_block);
     const int t2_first = 2 * r0 - 1, t2_last = 2 * (r1 - 1) + 1;
-    PatchEntry<TX> pe;
+    // the mel taps of a row are requested TWO rows before the row is computed (one row of SiLU work does not cover an L2 miss)
+    PatchEntry<TX> pe, pe2;
     pe.fetch(xb, F, T, F2, T2, t2_first, tid);
     pe.store(patch, tid);
+    pe.fetch(xb, F, T, F2, T2, t2_first + 1, tid);
     __syncthreads();
     for (int t2 = t2_first; t2 <= t2_last; ++t2) {
         const int buf = (t2 - t2_first) & 1;
         const char* pcur = patch + buf * PATCH_BYTES;
-        if (t2 < t2_last) pe.fetch(xb, F, T, F2, T2, t2 + 1, tid);          // next row's mel taps: in flight during this row
+        if (t2 + 1 < t2_last) pe2.fetch(xb, F, T, F2, T2, t2 + 2, tid);
         char* arow = act + ((t2 + 3) % 3) * SLOT;
 #pragma unroll
         for (int u = 0; u < NCB; ++u) {
@@ -150,6 +152,7 @@ __global__ __launch_bounds__(512, 4) void stage01_fwd_mfma_kernel(const TX* __re
             }
         }
         if (t2 < t2_last) pe.store(patch + (buf ^ 1) * PATCH_BYTES, tid);
+        pe = pe2;
         __syncthreads();                                   // row t2 of the window complete; next patch image complete
         if ((t2 & 1) == 0) continue;                       // depthwise rows are centred on even t2: run after row 2 t4 + 1
         const int t4 = (t2 - 1) >> 1;
@@ -158,7 +161,10 @@ __global__ __launch_bounds__(512, 4) void stage01_fwd_mfma_kernel(const TX* __re
         for (int u = 0; u < NCB; ++u) {
             if (wave + 8 * u >= ncb) break;
             const int c0 = (wave + 8 * u) * 32 + 2 * cp;
-            for (int f4 = fg; f4 < F4; f4 += 4) {
+#pragma unroll
+            for (int fi = 0; fi < 8; ++fi) {               // <= 32 outputs per row (F2 <= 64): independent chains, unrolled
+                const int f4 = fg + 4 * fi;
+                if (f4 >= F4) break;
                 float a0 = bd2[u][0], a1 = bd2[u][1];
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
@@ -329,17 +335,18 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
     };
 
     const int r0 = blockIdx.x * rows_per_block, r1 = min(T2, r0 + rows_per_block);     // r0 even
-    PatchEntry<TX> pe;
+    PatchEntry<TX> pe, pe2;
     pe.fetch(xb, F, T, F2, T2, r0, tid);
     gissue(r0 >> 1);
     pe.store(patch, tid);
+    pe.fetch(xb, F, T, F2, T2, r0 + 1, tid);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     for (int t2 = r0; t2 < r1; ++t2) {
         const int buf = (t2 - r0) & 1;
         const char* pcur = patch + buf * PATCH_BYTES;
         const bool odd = t2 & 1;
-        if (t2 + 1 < r1) pe.fetch(xb, F, T, F2, T2, t2 + 1, tid);
+        if (t2 + 2 < r1) pe2.fetch(xb, F, T, F2, T2, t2 + 2, tid);      // mel taps two rows ahead
         if (!odd) gissue((t2 >> 1) + 1);                   // the row the next (odd) conv0 row needs on top of this one's
         // dd1 rows of this conv0 row: even t2: to = t2/2 (tap row 1); odd: to = (t2+1)/2 (tap row 0) and (t2-1)/2 (tap row 2)
         const int toX = (odd ? t2 + 1 : t2) >> 1, toZ = (t2 - 1) >> 1;
@@ -412,6 +419,7 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
             }
         }
         if (t2 + 1 < r1) pe.store(patch + (buf ^ 1) * PATCH_BYTES, tid);
+        pe = pe2;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the dd1 row issued at the top of this (even) row has landed
         __syncthreads();
     }
