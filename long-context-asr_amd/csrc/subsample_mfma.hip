@@ -487,6 +487,7 @@ int sconf_dwconv_window_fwd(const void* x, const float* w, const float* bias, vo
     const int To = (int)((Ti - 1) / 2 + 1), Fo = (int)((Fi - 1) / 2 + 1);
     if (C % 32 != 0 || C > 512 || ((Fi + 1) / 2) * (C / 8) > 1024) return 0;
     if (const char* e = getenv("SCONF_SUB_MFMA")) if (e[0] == '0') return 0;                   // A/B switch (shared with the fused stage)
+    if (const char* e = getenv("SCONF_SUB_DW2")) if (e[0] == '0') return 0;                    // A/B switch of this kernel alone
     const size_t sh = 3 * (size_t)(Fi / 2 + 2) * (4 * C + 128);
     if (sh > 160 * 1024) return 0;
     long target = 4096;

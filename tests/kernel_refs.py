@@ -329,10 +329,16 @@ def sub_conv0_fwd(x, w, bias):
     return y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
 
+def _q(t):
+    """bf16 operand rounding of the MFMA / v_dot2c kernels (the gradient passes straight through the casts)."""
+    return t.to(torch.bfloat16).to(f32)
+
+
 def sub_dwconv_fwd(x, w, bias):
+    # rounding points of dwconv_window_fwd_kernel: SiLU values stored as bf16 pairs, taps as bf16 (v_dot2c_f32_bf16), f32 sums
     Cc = x.shape[-1]
-    xf = F.silu(x.to(f32)).permute(0, 3, 1, 2)
-    y = F.conv2d(xf, w.reshape(Cc, 1, 3, 3), bias, stride=2, padding=1, groups=Cc)
+    xf = _q(F.silu(x.to(f32))).permute(0, 3, 1, 2)
+    y = F.conv2d(xf, _q(w).reshape(Cc, 1, 3, 3), bias, stride=2, padding=1, groups=Cc)
     return y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
 
@@ -359,9 +365,11 @@ def sub_conv0_bwd_(dpre0, x, dw, dbias):
 
 
 def _stage01(x, w0, b0, wd, bd):
+    # rounding points of the MFMA kernels (subsample_mfma.hip): mel and conv0 taps as bf16 MFMA operands (bias as hi + lo: exact
+    # enough to be f32 here), stage-0 activations stored as bf16, depthwise taps as bf16, f32 accumulation everywhere
     Cc = w0.shape[0]
-    y0 = F.conv2d(x.to(f32).transpose(1, 2).unsqueeze(1), w0.reshape(Cc, 1, 3, 3), b0, stride=2, padding=1)
-    return F.conv2d(F.silu(y0), wd.reshape(Cc, 1, 3, 3), bd, stride=2, padding=1, groups=Cc).permute(0, 2, 3, 1)
+    y0 = F.conv2d(_q(x.to(f32)).transpose(1, 2).unsqueeze(1), _q(w0).reshape(Cc, 1, 3, 3), b0, stride=2, padding=1)
+    return F.conv2d(_q(F.silu(y0)), _q(wd).reshape(Cc, 1, 3, 3), bd, stride=2, padding=1, groups=Cc).permute(0, 2, 3, 1)
 
 
 def sub_stage01_fwd(x, w0, b0, wd, bd):
