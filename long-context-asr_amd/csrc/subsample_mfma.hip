@@ -45,14 +45,12 @@ template <typename TX> struct PatchEntry {
         float v[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
-            const int k = 2 * kp + e;
-            float val = 0.f;
-            if (k < 9) {
-                const int a = k / 3, b = k - 3 * a, t = 2 * t2 + a - 1, f = 2 * pos + b - 1;
-                const float m = ld_f(xb + (long)min(max(f, 0), F - 1) * T + min(max(t, 0), T - 1));
-                val = (row_ok && t >= 0 && t < T && f >= 0 && f < F) ? m : 0.f;
-            } else if (k < 11) val = row_ok ? 1.f : 0.f;       // bias columns: a padding position's pre-activation is exactly 0
-            v[e] = val;
+            const int k = 2 * kp + e, kc = min(k, 8);          // the load is unconditional (a branch around it costs a round trip per lane group)
+            const int a = kc / 3, b = kc - 3 * a, t = 2 * t2 + a - 1, f = 2 * pos + b - 1;
+            const float m = ld_f(xb + (long)min(max(f, 0), F - 1) * T + min(max(t, 0), T - 1));
+            const float tap = (row_ok && t >= 0 && t < T && f >= 0 && f < F) ? m : 0.f;
+            const float one = row_ok ? 1.f : 0.f;              // bias columns 9, 10: a padding position's pre-activation is exactly 0
+            v[e] = k < 9 ? tap : (k < 11 ? one : 0.f);
         }
         v0 = v[0]; v1 = v[1];
     }
@@ -294,9 +292,9 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
                                                                   float* __restrict__ dw0, float* __restrict__ db0, float* __restrict__ dwd, float* __restrict__ dbd,
                                                                   int F, int T, int C, int T2, int F2, int T4, int F4, int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int GS = 2 * C, GSLOT = ((F4 * GS + 512 * 16 - 1) / (512 * 16)) * (512 * 16);   // whole DMA passes of the workgroup
+    const int GS = 2 * C, GSLOT = (F4 + 2) * GS;          // a dd1 row + two zero bins (fo = F4, F4 + 1: taps past the last output)
     char* patch = smem;                                  // [2][PATCH_BYTES]
-    char* gimg = smem + 2 * PATCH_BYTES;                 // [2][F4][C] bf16
+    char* gimg = smem + 2 * PATCH_BYTES;                 // [3][F4 + 2][C] bf16: slots to & 1, slot 2 = zeros (rows outside [0, T4))
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5, cl = lane & 31;
     const int b = blockIdx.y;
     const TX* xb = x + (long)b * F * T;
@@ -320,17 +318,23 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
 
     // one dd1 row `to` ([F4][C] bf16, contiguous) -> LDS slot to & 1 by LDS-DMA issued from inline asm (no staging registers, no
     // ds_write, invisible to hipcc's vmcnt bookkeeping: waited for by hand before the barrier that publishes it).  Rows outside
-    // [0, T4) are clamped here and masked where they are used.
+    // [0, T4) are not copied: their users read the all-zero slot 2; bins >= F4 of every slot stay zero (set once below) - so the
+    // tap reads need neither clamps nor selects.
+    for (int i = tid; i < 3 * GSLOT / 4; i += 512) *reinterpret_cast<unsigned*>(gimg + i * 4) = 0u;
+    __syncthreads();                                     // before any wave's DMA can land in a slot another wave is still zeroing
     const unsigned lds_g = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)gimg);
     const int gchunks = F4 * C / 8;                       // 16-byte pieces per row
     auto gissue = [&](int to) {
-        const bf16* src = gb + (long)min(max(to, 0), T4 - 1) * F4 * C;
+        if (to < 0 || to >= T4) return;                                        // uniform
+        const bf16* src = gb + (long)to * F4 * C;
         const unsigned dst = lds_g + (unsigned)((to & 1) * GSLOT) + (unsigned)__builtin_amdgcn_readfirstlane(tid & ~63) * 16u;
         for (int i = 0; i * 512 < gchunks; ++i) {
-            const int ch = min(tid + 512 * i, gchunks - 1);                    // the tail re-copies the last piece (same bytes)
-            unsigned keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src + (long)ch * 8), "s"(dst + (unsigned)(i * 512 * 16)) : "memory");
+            const int ch = tid + 512 * i;
+            if (ch < gchunks) {                                                // lanes past the row stay out (the zero bins follow it)
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src + (long)ch * 8), "s"(dst + (unsigned)(i * 512 * 16)) : "memory");
+            }
         }
     };
 
@@ -350,9 +354,8 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
         if (!odd) gissue((t2 >> 1) + 1);                   // the row the next (odd) conv0 row needs on top of this one's
         // dd1 rows of this conv0 row: even t2: to = t2/2 (tap row 1); odd: to = (t2+1)/2 (tap row 0) and (t2-1)/2 (tap row 2)
         const int toX = (odd ? t2 + 1 : t2) >> 1, toZ = (t2 - 1) >> 1;
-        const char* gX = gimg + (toX & 1) * GSLOT;        // tap row 1 (even) / 0 (odd)
-        const char* gZ = gimg + (toZ & 1) * GSLOT;        // tap row 2 (odd rows only)
-        const bool okX = toX < T4;                        // (toZ >= 0 always: odd t2 >= 1; toX >= 0)
+        const char* gX = gimg + (toX < T4 ? (toX & 1) : 2) * GSLOT;    // tap row 1 (even) / 0 (odd); past the tensor: the zero slot
+        const char* gZ = gimg + (toZ & 1) * GSLOT;                       // tap row 2 (odd rows only; toZ >= 0 always)
 #pragma unroll
         for (int u = 0; u < NCB; ++u) {
             if (wave + 8 * u >= ncb) break;
@@ -373,12 +376,11 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
                     float sg[4], sv[4], gs[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) { const float v = pre[4 * g4 + e]; sg[e] = sigmoidf_(v); sv[e] = v * sg[e]; gs[e] = 0.f; }
-                    auto taps = [&](const char* grow, int i, bool row_ok) {   // one dd1 row, tap row i: fo = 2p, 2p+1, 2p+2 serve f2 = base..base+3
-                        const unsigned short* gp_ = reinterpret_cast<const unsigned short*>(grow + c * 2);
-                        const unsigned u0 = gp_[min(2 * p, F4 - 1) * C], u1 = gp_[min(2 * p + 1, F4 - 1) * C], u2 = gp_[min(2 * p + 2, F4 - 1) * C];
-                        const float g0 = (row_ok && 2 * p < F4) ? __builtin_bit_cast(float, u0 << 16) : 0.f;
-                        const float g1 = (row_ok && 2 * p + 1 < F4) ? __builtin_bit_cast(float, u1 << 16) : 0.f;
-                        const float g2 = (row_ok && 2 * p + 2 < F4) ? __builtin_bit_cast(float, u2 << 16) : 0.f;
+                    auto taps = [&](const char* grow, int i) {   // one dd1 row, tap row i: fo = 2p, 2p+1, 2p+2 serve f2 = base..base+3
+                        const unsigned short* gp_ = reinterpret_cast<const unsigned short*>(grow + (2 * p) * GS + c * 2);
+                        const float g0 = __builtin_bit_cast(float, (unsigned)gp_[0] << 16);
+                        const float g1 = __builtin_bit_cast(float, (unsigned)gp_[C] << 16);
+                        const float g2 = __builtin_bit_cast(float, (unsigned)gp_[2 * C] << 16);
                         const float* w = wd[u] + 3 * i;
                         float* gw = gwd[u] + 3 * i;
                         // f2 = base   (even): j = 1, fo = 2p        f2 = base+1 (odd): j = 0, fo = 2p+1;  j = 2, fo = 2p
@@ -389,8 +391,8 @@ __global__ __launch_bounds__(512, (NCB == 1 ? 4 : 2)) void stage01_bwd_mfma_kern
                         gs[3] += w[0] * g2 + w[2] * g1;     gw[0] += g2 * sv[3]; gw[2] += g1 * sv[3];
                         if (i == 1) gbd[u] += g0 + g1;      // the centre tap visits every dd1 element exactly once
                     };
-                    if (!odd) taps(gX, 1, okX);
-                    else { taps(gX, 0, okX); taps(gZ, 2, true); }
+                    if (!odd) taps(gX, 1);
+                    else { taps(gX, 0); taps(gZ, 2); }
                     float d4[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -468,8 +470,8 @@ int sconf_stage01_bwd_mfma(const void* dd1, const void* x, int x_dtype, const fl
     if (C % 32 != 0 || C > 512 || F2 > PPOS) return 0;
     if (const char* e = getenv("SCONF_SUB_MFMA")) if (e[0] == '0') return 0;                   // A/B switch
     if ((F4 * C) % 8 != 0) return 0;
-    const size_t gslot = (((size_t)F4 * 2 * C + 512 * 16 - 1) / (512 * 16)) * (512 * 16);
-    const size_t sh = 2 * (size_t)PATCH_BYTES + 2 * gslot;
+    const size_t gslot = (size_t)(F4 + 2) * 2 * C;
+    const size_t sh = 2 * (size_t)PATCH_BYTES + 3 * gslot;
     if (sh > 64 * 1024) return 0;
     long target = 2048;
     if (const char* e = getenv("SCONF_SUB_BWD_BLOCKS")) target = atol(e);                       // tuning
