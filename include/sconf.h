@@ -128,6 +128,7 @@ int sconf_sub_conv0_fwd(const void* x, int x_dtype, const float* w, const float*
 int sconf_sub_dwconv_fwd(const void* x, const float* w, const float* bias, void* y, int64_t B, int64_t Ti, int64_t Fi,
                          int64_t C, sconf_stream_t stream);
 int sconf_sub_dwconv_bwd(const void* dout, const float* w, const void* pre_in, void* dpre_in, float* dw, float* dbias,
+                         float* dpre_colsum /*nullable, f32 [C], accumulated: column sums of dpre_in = bias gradient of the 1x1 conv before it*/,
                          int64_t B, int64_t Ti, int64_t Fi, int64_t C, sconf_stream_t stream);
 int sconf_sub_conv0_bwd(const void* dpre0, const void* x, int x_dtype, float* dw, float* dbias, int64_t B, int64_t F,
                         int64_t T, int64_t C, sconf_stream_t stream);

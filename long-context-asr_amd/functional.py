@@ -580,9 +580,10 @@ class SubsampleFn(Function):
         dbp2 = _bgrad(dpre2, pbp2)
         dd2 = ops.gemm(dpre2, wp2t, 'nt').view(d2.shape)
         dwd2, dbd2 = _G(pwd2, (C, 9)), _G(pbd2)
-        dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2.t, dbd2.t).view(-1, C)
+        gbp1 = _G(pbp1)                                                                # its bias gradient = column sums of dpre1: same pass
+        dpre1 = ops.sub_dwconv_bwd(dd2, wd2f, pre1, dwd2.t, dbd2.t, colsum_into=gbp1.t).view(-1, C)
         dwp1 = _wgrad(dpre1, d1.view(-1, C), pwp1)
-        dbp1 = _bgrad(dpre1, pbp1)
+        dbp1 = gbp1.out()
         dd1 = ops.gemm(dpre1, wp1t, 'nt').view(d1.shape)
         dwd1, dbd1, dw0, db0 = _G(pwd1, (C, 9)), _G(pbd1), _G(pw0, (C, 9)), _G(pb0)
         ops.sub_stage01_bwd_(dd1, audio, w0f, b0, wd1f, dw0.t, db0.t, dwd1.t, dbd1.t)  # conv0 recomputed; no (B,T/2,F/2,C) grads

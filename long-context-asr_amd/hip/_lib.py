@@ -37,7 +37,7 @@ PROTOTYPES = {
     'sconf_convmod_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, f32, vp],
     'sconf_sub_conv0_fwd': [vp, i32, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_dwconv_fwd': [vp, vp, vp, vp, i64, i64, i64, i64, vp],
-    'sconf_sub_dwconv_bwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
+    'sconf_sub_dwconv_bwd': [vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_conv0_bwd': [vp, vp, i32, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_stage01_fwd': [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_stage01_bwd': [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],

@@ -387,11 +387,16 @@ def sub_dwconv_fwd(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor) -> torc
     return y
 
 
-def sub_dwconv_bwd(dout: torch.Tensor, w: torch.Tensor, pre_in: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor) -> torch.Tensor:
+def sub_dwconv_bwd(dout: torch.Tensor, w: torch.Tensor, pre_in: torch.Tensor, dw: torch.Tensor, dbias: torch.Tensor,
+                   colsum_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """colsum_into (f32, C elements): += column sums of the returned dpre (the bias gradient of the 1x1 conv that produced pre_in)."""
     _chk(dout, 'dout', torch.bfloat16); _chk(pre_in, 'pre_in', torch.bfloat16)
     B, Ti, Fi, Cc = pre_in.shape
     dpre = torch.empty_like(pre_in)
-    _lib.call('sconf_sub_dwconv_bwd', _p(dout), _p(w), _p(pre_in), _p(dpre), _p(dw), _p(dbias), B, Ti, Fi, Cc, _stream())
+    if colsum_into is not None:
+        _chk(colsum_into, 'colsum_into', torch.float32)
+        if colsum_into.numel() != Cc: raise ValueError('colsum_into must have one element per channel')
+    _lib.call('sconf_sub_dwconv_bwd', _p(dout), _p(w), _p(pre_in), _p(dpre), _p(dw), _p(dbias), _p(colsum_into), B, Ti, Fi, Cc, _stream())
     return dpre
 
 

@@ -342,7 +342,7 @@ def sub_dwconv_fwd(x, w, bias):
     return y.permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
 
 
-def sub_dwconv_bwd(dout, w, pre_in, dw, dbias):
+def sub_dwconv_bwd(dout, w, pre_in, dw, dbias, colsum_into=None):
     Cc = pre_in.shape[-1]
     p = pre_in.to(f32).detach().clone().requires_grad_(True)
     wf = w.detach().clone().reshape(Cc, 1, 3, 3).requires_grad_(True)
@@ -351,7 +351,9 @@ def sub_dwconv_bwd(dout, w, pre_in, dw, dbias):
         y = F.conv2d(F.silu(p).permute(0, 3, 1, 2), wf, bf_, stride=2, padding=1, groups=Cc).permute(0, 2, 3, 1)
         y.backward(dout.to(f32))
     dw += wf.grad.reshape(dw.shape); dbias += bf_.grad
-    return p.grad.to(torch.bfloat16)
+    out = p.grad.to(torch.bfloat16)
+    if colsum_into is not None: colsum_into += out.to(f32).reshape(-1, Cc).sum(0).view(colsum_into.shape)
+    return out
 
 
 def sub_conv0_bwd_(dpre0, x, dw, dbias):

@@ -431,9 +431,11 @@ def test_subsample_ops(ops, B, T, C):
     dout = rnd(*d1r.shape, seed=5)
     dw, db = torch.zeros(C, 9).cuda(), torch.zeros(C).cuda()
     dwr, dbr = torch.zeros(C, 9), torch.zeros(C)
-    dpre = ops.sub_dwconv_bwd(dev(dout), dev(wd), dev(pre0r), dw, db)
+    cs = torch.full((C,), 0.5, device='cuda')                      # accumulated into: the bias gradient of the 1x1 conv before it
+    dpre = ops.sub_dwconv_bwd(dev(dout), dev(wd), dev(pre0r), dw, db, colsum_into=cs)
     dprer = R.sub_dwconv_bwd(dout, wd, pre0r, dwr, dbr)
     close(dpre, dprer, name='dwconv bwd input'); close(dw, dwr, name='dwconv dw', tol=5e-3); close(db, dbr, name='dwconv db', tol=5e-3)
+    close(cs - 0.5, dpre.float().reshape(-1, C).sum(0), name='dwconv bwd column sums', tol=2e-3)
     dw0, db0 = torch.zeros(C, 9).cuda(), torch.zeros(C).cuda()
     dw0r, db0r = torch.zeros(C, 9), torch.zeros(C)
     ops.sub_conv0_bwd_(dev(dprer), dev(x), dw0, db0)
