@@ -203,14 +203,16 @@ def _pre(x, nw, nb, mode, eps):
     return ops.norm_fwd(x, nw, nb, mode, eps, BF16)
 
 
-def _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dres, dnw, dnb):
-    """norm backward of a residual branch: dx = dres + norm'(x) dh (f32), with the bf16 twin parked for the receiving block."""
+def _norm_bwd_res(dh, x, nw, mean, rstd, mode, eps, dres, dnw, dnb, twin=True):
+    """norm backward of a residual branch: dx = dres + norm'(x) dh (f32), with the bf16 twin parked for the receiving block
+    (twin=False when the receiver is not a GEMM block: the self-conditioning block hands its dx to norm_out's backward, which
+    reads the f32 tensor)."""
     if mode == 'none':
         if dres is not None:
             raise RuntimeError('a block without its PreNorm has no fused residual')
         return ops.cast(dh, x.dtype)
-    if dres is None:
-        return ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, None, F32, dnw, dnb)
+    if dres is None or not twin:
+        return ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dres, F32, dnw, dnb)
     dx, dx16, cs = ops.norm_bwd(dh, x, nw, mean, rstd, mode, eps, dres, F32, dnw, dnb, twin=True)
     _park_twin(dx, dx16, cs)
     return dx
@@ -481,7 +483,7 @@ class SelfCondFn(Function):
         dhn = ops.gemm(dl, wft, 'nt')
         if has_norm:
             dnw, dnb = _G(pnw), _G(pnb)
-            dx = _norm_bwd_res(dhn, x, nw, mean, rstd, mode, eps, dy, dnw.t, dnb.t)
+            dx = _norm_bwd_res(dhn, x, nw, mean, rstd, mode, eps, dy, dnw.t, dnb.t, twin=False)
             return dx, dnw.out(), dnb.out(), dwf, dbf, dwr, dbr, None, None, None
         dx = dy + ops.cast(dhn, F32)
         return dx, None, None, dwf, dbf, dwr, dbr, None, None, None
