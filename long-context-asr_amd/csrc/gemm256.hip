@@ -309,21 +309,21 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
 // `kind` is computed once per launch (wave-uniform), everything else takes the runtime-flag path.
 //   0 bf16 plain   1 bf16 + bias   2 f32 + residual   3 f32 + residual + bias   4 gelu' save (no bias)   5 * aux   6 generic
 __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
-    const bool b = p.bias != nullptr;
-    if (p.act == SCONF_ACT_GELU_DSAVE) return (!b && !p.out_f32 && !p.resid) ? 4 : 6;
+    const bool b = p.bias != nullptr, unit = p.alpha == 1.f;   // kinds 0, 1, 4 skip the alpha * v + residual step (the FF dgrad, kind 5, carries the branch scale in alpha)
+    if (p.act == SCONF_ACT_GELU_DSAVE) return (!b && !p.out_f32 && !p.resid && unit) ? 4 : 6;
     if (p.act == SCONF_ACT_MULAUX) return (!b && !p.out_f32 && !p.resid && !p.pre) ? 5 : 6;
     if (p.act != SCONF_ACT_NONE || p.pre) return 6;
-    if (!p.out_f32 && !p.resid) return b ? 1 : 0;
+    if (!p.out_f32 && !p.resid) return unit ? (b ? 1 : 0) : 6;
     if (p.out_f32 && p.resid) return b ? 3 : 2;
     return 6;
 }
 #define EPILOGUE_NT(JH_)                                                                                              \
     switch (ekind) {                                                                                                  \
-        case 0: epilogue256<SCONF_ACT_NONE, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;                  \
-        case 1: epilogue256<SCONF_ACT_NONE, false, false, JH_, 1>(p, acc, cit, wr, wc, lane); break;                  \
+        case 0: epilogue256<SCONF_ACT_NONE, false, false, JH_, 4>(p, acc, cit, wr, wc, lane); break;                  \
+        case 1: epilogue256<SCONF_ACT_NONE, false, false, JH_, 5>(p, acc, cit, wr, wc, lane); break;                  \
         case 2: epilogue256<SCONF_ACT_NONE, true, false, JH_, 2>(p, acc, cit, wr, wc, lane); break;                   \
         case 3: epilogue256<SCONF_ACT_NONE, true, false, JH_, 3>(p, acc, cit, wr, wc, lane); break;                   \
-        case 4: epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;            \
+        case 4: epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_, 4>(p, acc, cit, wr, wc, lane); break;            \
         case 5: epilogue256<SCONF_ACT_MULAUX, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;                \
         default:                                                                                                      \
             if (p.act == SCONF_ACT_GELU_DSAVE)  epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_>(p, acc, cit, wr, wc, lane); \

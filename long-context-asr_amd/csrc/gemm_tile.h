@@ -57,7 +57,8 @@ template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, E
 // work item, so that the instructions an item executes are contiguous); ACT = -1 reads p.act.  bs / ax / rs are the run's
 // bias, aux and residual values (zeros where absent), loaded by the caller - ahead of any store where it matters: on gfx950
 // loads and stores retire through one in-order counter, so a load issued behind a store waits for that store's completion.
-// FL >= 0 also fixes, at compile time, whether a bias is added (bit 0) and whether the output is f32 (bit 1), and promises that
+// FL >= 0 also fixes, at compile time, whether a bias is added (bit 0), whether the output is f32 (bit 1) and whether the final
+// alpha * v + residual step is the identity (bit 2: alpha == 1, no residual), and promises that
 // p.pre is only used by GELU_DSAVE: with those known the compiler emits no branch and - the point - no conservative
 // `s_waitcnt vmcnt(0)` in front of each bias use (which drained the stores of the previous row every time).  coff / poff are
 // the element offsets of the run in C and in pre (row offset computed once per row block by the caller).
@@ -99,8 +100,10 @@ __device__ __forceinline__ void epi_math_store_at(const GemmParams& p, float (&v
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] *= dsiluf_(ax[e]);
     }
+    if (!(FL >= 0 && (FL & 4))) {                    // FL bit 2: alpha == 1 and no residual (epilogue_kind checks) - nothing to do
 #pragma unroll
-    for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + rs[e];
+        for (int e = 0; e < W; ++e) v[e] = v[e] * p.alpha + rs[e];
+    }
     if (!st) return;
     if (f32o) storev<W>(reinterpret_cast<float*>(p.C) + split * p.split_stride + coff, v);
     else      storev<W>(reinterpret_cast<bf16*>(p.C) + coff, v);
