@@ -30,11 +30,21 @@ class ASRLinearSCDecoder(nn.Module):
         y = Fn.decoder_head(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, n_norms, mode, eps, logits)
         return y.view(*shape[:-1], self.num_classes)
 
-    def self_condition(self, x):
-        """x + reprojection(softmax(ff(norm(x))))  (sconformer_xl.py:241-243)."""
+    def post_norm_spec(self, d_model, producer_mode):
+        """What a layer needs to apply this decoder's norm together with its own `norm_out` (Fn.norm2): a dict the layer fills with
+        'h' = norm(layer output) in bf16, or None when the pair cannot be fused (no norm, not LayerNorm, rows wider than 768)."""
+        if not self.has_norm or not Fn.norm2_enabled(d_model, producer_mode, self.norm.mode):
+            return None
+        nw, nb = self._np()
+        return {'w': nw, 'b': nb, 'eps': self.norm.eps}
+
+    def self_condition(self, x, prenormed=None):
+        """x + reprojection(softmax(ff(norm(x))))  (sconformer_xl.py:241-243).  prenormed: norm(x) in bf16 if the producer of x
+        has already applied this decoder's norm (post_norm_spec)."""
         shape = x.shape
         nw, nb = self._np()
         mode, eps = (self.norm.mode, self.norm.eps) if self.has_norm else ('layer_norm', 1e-5)
         y = Fn.selfcond_block(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, self.reprojection.weight,
-                              self.reprojection.bias, self.has_norm, mode, eps)
+                              self.reprojection.bias, self.has_norm, mode, eps,
+                              prenormed=None if prenormed is None else prenormed.reshape(-1, shape[-1]))
         return y.view(shape)

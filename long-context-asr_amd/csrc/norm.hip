@@ -287,6 +287,244 @@ int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Two LayerNorms back to back, y1 = LN(x; w1, b1) (f32, kept: it is the layer's output and the residual of what follows) and
+// h2 = LN(y1; w2, b2) (bf16, the operand of the next projection): `norm_out` of a ConformerLayer followed by the decoder norm of the
+// self-conditioning step or of the head (sconformer_xl.py:371, 241-247; decoder.py:23).  Both kernels are HBM-bound and the two
+// single norms run at the HBM roofline already, so what the fusion buys is bytes: forward 10 instead of 14 B per element (y1 is
+// not re-read), backward 16 instead of 28 (the gradient of y1 never exists in memory, and y1 itself is recomputed from x and the
+// saved row statistics instead of being read).
+template <int MAXIT>
+__global__ __launch_bounds__(256) void norm2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
+                                                        const float* __restrict__ w2, const float* __restrict__ b2,
+                                                        float* __restrict__ y1, bf16* __restrict__ h2, float* __restrict__ mean1,
+                                                        float* __restrict__ rstd1, float* __restrict__ mean2, float* __restrict__ rstd2,
+                                                        int M, int d, float eps1, float eps2) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (long)row * d;
+    float v[MAXIT][4];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) { load4(xr + c, v[it]); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
+        else { v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f; }
+    }
+    // the same two-pass statistics as norm_fwd_kernel, twice
+    auto stats = [&](float sum, float eps, float& mean, float& rstd) {
+        mean = wave_sum(sum) / d;
+        float q = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const float t = v[it][e] - mean; q += t * t; }
+            }
+        }
+        rstd = rsqrtf(wave_sum(q) / d + eps);
+    };
+    float m1, r1, m2, r2;
+    stats(s, eps1, m1, r1);
+    float* yr = y1 + (long)row * d;
+    s = 0.f;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            float wv[4], bv[4]; load4(w1 + c, wv); load4(b1 + c, bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[it][e] = (v[it][e] - m1) * r1 * wv[e] + bv[e];
+            store4(yr + c, v[it]);
+            s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+        }
+    }
+    stats(s, eps2, m2, r2);
+    if (lane == 0) { mean1[row] = m1; rstd1[row] = r1; mean2[row] = m2; rstd2[row] = r2; }
+    bf16* hr = h2 + (long)row * d;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = it * 256 + lane * 4;
+        if (c < d) {
+            float wv[4], bv[4], o[4]; load4(w2 + c, wv); load4(b2 + c, bv);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (v[it][e] - m2) * r2 * wv[e] + bv[e];
+            store4(hr + c, o);
+        }
+    }
+}
+
+// Backward of the pair.  dh2: gradient of h2 (bf16); dres: gradient that reaches y1 directly (f32, nullable).  Per row:
+//   y1 = xhat1 w1 + b1 (recomputed), xhat2 = (y1 - mean2) rstd2,  dy1 = dres + LN'(dh2 at y1),  dx = LN'(dy1 at x).
+// Parameter gradients of both norms and the column sums of the bf16 twin go to the workgroup's slab [5][d]
+// (dw1 | db1 | dw2 | db2 | colsum), added up in a fixed order by norm2_bwd_reduce_kernel.
+template <int MAXIT, int NB_WAVES>
+__global__ __launch_bounds__(64 * NB_WAVES) void norm2_bwd_kernel(const bf16* __restrict__ dh2, const float* __restrict__ x,
+                                                          const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ mean1, const float* __restrict__ rstd1,
+                                                          const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                          const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ ws,
+                                                          bf16* __restrict__ dx16, int M, int d) {
+    const int lane = threadIdx.x & 63;
+    const int wid = blockIdx.x * NB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * NB_WAVES;
+    float aw1[MAXIT][4], ab1[MAXIT][4], aw2[MAXIT][4], ab2[MAXIT][4], ac[MAXIT][4], w1v[MAXIT][4], w2v[MAXIT][4];
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        const int c = it * 256 + lane * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { aw1[it][e] = ab1[it][e] = aw2[it][e] = ab2[it][e] = ac[it][e] = 0.f; w1v[it][e] = w2v[it][e] = 0.f; }
+        if (c < d) { load4(w1 + c, w1v[it]); load4(w2 + c, w2v[it]); }
+    }
+    struct Row { Raw4<float> x[MAXIT]; Raw4<bf16> g[MAXIT]; Raw4<float> r[MAXIT]; float m1, r1, m2, r2; };
+    auto load_row = [&](Row& R, int row) {
+        R.m1 = mean1[row]; R.r1 = rstd1[row]; R.m2 = mean2[row]; R.r2 = rstd2[row];
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                raw_load(R.x[it], x + (long)row * d + c); raw_load(R.g[it], dh2 + (long)row * d + c);
+                if (dres) raw_load(R.r[it], dres + (long)row * d + c);
+            }
+        }
+    };
+    Row nxt;
+    if (wid < M) load_row(nxt, wid);
+    for (int row = wid; row < M; row += nw) {
+        Row cur = nxt;
+        if (row + nw < M) load_row(nxt, row + nw);
+        float xh1[MAXIT][4], t[MAXIT][4];                  // t: xhat2, then dy1
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                float xv[4], g[4], bv[4];
+                cur.x[it].get(xv); cur.g[it].get(g); load4(b1 + c, bv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x1 = (xv[e] - cur.m1) * cur.r1;
+                    xh1[it][e] = x1;
+                    const float x2 = (x1 * w1v[it][e] + bv[e] - cur.m2) * cur.r2;
+                    const float gw = g[e] * w2v[it][e];
+                    s1 += gw; s2 += gw * x2;
+                    aw2[it][e] += g[e] * x2; ab2[it][e] += g[e];
+                    t[it][e] = x2;
+                }
+            }
+        }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        const float c1 = cur.r2 * s1 / d, c2 = cur.r2 * s2 / d;
+        float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                float g[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+                cur.g[it].get(g);
+                if (dres) cur.r[it].get(r);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float dy1 = r[e] + cur.r2 * g[e] * w2v[it][e] - c1 - t[it][e] * c2;
+                    t[it][e] = dy1;
+                    const float gw = dy1 * w1v[it][e];
+                    u1 += gw; u2 += gw * xh1[it][e];
+                    aw1[it][e] += dy1 * xh1[it][e]; ab1[it][e] += dy1;
+                }
+            }
+        }
+        u1 = wave_sum(u1); u2 = wave_sum(u2);
+        const float e1 = cur.r1 * u1 / d, e2 = cur.r1 * u2 / d;
+        float* dxr = dx + (long)row * d;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                float o[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = cur.r1 * t[it][e] * w1v[it][e] - e1 - xh1[it][e] * e2;
+                store4(dxr + c, o);
+                if (dx16) {
+                    store4(dx16 + (long)row * d + c, o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) ac[it][e] += (float)(bf16)o[e];
+                }
+            }
+        }
+    }
+    __shared__ float red[NB_WAVES][256];
+    const int wvi = threadIdx.x >> 6;
+#pragma unroll
+    for (int it = 0; it < MAXIT; ++it) {
+        if (it * 256 >= d) break;                                   // uniform
+        const int c = it * 256 + lane * 4;
+#pragma unroll
+        for (int pass = 0; pass < 5; ++pass) {
+            if (pass == 4 && !dx16) continue;                       // uniform
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                red[wvi][lane * 4 + e] = pass == 0 ? aw1[it][e] : pass == 1 ? ab1[it][e] : pass == 2 ? aw2[it][e] : pass == 3 ? ab2[it][e] : ac[it][e];
+            __syncthreads();
+            if (wvi == 0 && c < d) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[e] = 0.f;
+#pragma unroll
+                    for (int k = 0; k < NB_WAVES; ++k) v[e] += red[k][lane * 4 + e];
+                }
+                store4(ws + ((long)blockIdx.x * 5 + pass) * d + c, v);
+            }
+        }
+    }
+}
+
+// outs[pass][c] (+)= sum_b ws[b][pass][c] for the five slabs of norm2_bwd_kernel (the colsum slab overwrites, the rest accumulate)
+struct Norm2Outs { float* p[5]; };
+__global__ __launch_bounds__(1024) void norm2_bwd_reduce_kernel(const float* __restrict__ ws, Norm2Outs outs, int nblocks, int d) {
+    __shared__ float red[16][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int col = blockIdx.x * 64 + lane;                          // in [0, 5d)
+    const int pass = col / d, c = col - pass * d;
+    float* const outp = pass < 5 ? outs.p[pass] : nullptr;
+    const bool live = col < 5 * d && outp != nullptr;
+    float a = 0.f;
+    if (live) {
+        float t[4] = {0.f, 0.f, 0.f, 0.f};
+        int b = wv;
+        for (; b + 48 < nblocks; b += 64) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[u] += ws[((long)(b + 16 * u) * 5 + pass) * d + c];
+        }
+        for (; b < nblocks; b += 16) t[0] += ws[((long)b * 5 + pass) * d + c];
+        a = (t[0] + t[1]) + (t[2] + t[3]);
+    }
+    red[wv][lane] = a;
+    __syncthreads();
+    if (wv == 0 && live) {
+        float v = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][lane];
+        if (pass == 4) outp[c] = v; else outp[c] += v;
+    }
+}
+
+template <int NIT> int launch_norm2_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, bf16* h2,
+                                        float* mean1, float* rstd1, float* mean2, float* rstd2, int M, int d, float eps1, float eps2, hipStream_t st) {
+    hipLaunchKernelGGL((norm2_fwd_kernel<NIT>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, w1, b1, w2, b2, y1, h2, mean1, rstd1, mean2, rstd2, M, d, eps1, eps2);
+    return 0;
+}
+template <int NIT> int launch_norm2_bwd(const bf16* dh2, const float* x, const float* w1, const float* b1, const float* w2, const float* mean1,
+                                        const float* rstd1, const float* mean2, const float* rstd2, const float* dres, float* dx, float* ws,
+                                        bf16* dx16, int grid, int M, int d, hipStream_t st) {
+    hipLaunchKernelGGL((norm2_bwd_kernel<NIT, NBW>), dim3(grid), dim3(64 * NBW), 0, st, dh2, x, w1, b1, w2, mean1, rstd1, mean2, rstd2, dres, dx, ws, dx16, M, d);
+    return 0;
+}
+#define NIT_DISPATCH1(FN, ...) do { const int nit_ = (int)((d + 255) / 256); \
+    if (nit_ <= 1) FN<1>(__VA_ARGS__); else if (nit_ <= 2) FN<2>(__VA_ARGS__); else FN<3>(__VA_ARGS__); } while (0)   /* d <= 768: wider rows spill in the backward */
+
 #define NIT_DISPATCH(FN, MODE_, ...) do { const int nit_ = (int)((d + 255) / 256); \
     if (nit_ <= 1) FN<MODE_, 1>(__VA_ARGS__); else if (nit_ <= 2) FN<MODE_, 2>(__VA_ARGS__); else if (nit_ <= 3) FN<MODE_, 3>(__VA_ARGS__); \
     else if (nit_ <= 4) FN<MODE_, 4>(__VA_ARGS__); else FN<MODE_, 8>(__VA_ARGS__); } while (0)
@@ -327,5 +565,38 @@ SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void*
     else if (mode == 1) NIT_DISPATCH(launch_bwd, 1, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (bf16*)dx_bf16, dx_colsum, (int)M, (int)d, eps, stream);
     else NIT_DISPATCH(launch_bwd, 2, dy, dy_dtype, x, x_dtype, weight, mean, rstd, dres, dx, dx_dtype, dweight, dbias, workspace, (long)workspace_floats, (bf16*)dx_bf16, dx_colsum, (int)M, (int)d, eps, stream);
     SCONF_LAUNCH_OK("sconf_norm_bwd");
+    return 0;
+}
+
+// y1 = LayerNorm(x; w1, b1) (f32) and h2 = LayerNorm(y1; w2, b2) (bf16) in one pass over x; the four row statistics are saved for
+// sconf_norm2_bwd.  Replaces `norm_out` + the decoder norm that follows it (sconformer_xl.py:371 then 241-247 / decoder.py:23).
+SCONF_API int sconf_norm2_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, void* h2_bf16,
+                              float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t M, int64_t d, float eps1, float eps2,
+                              hipStream_t stream) {
+    SCONF_REQUIRE(d % 4 == 0 && d <= 768 && d > 0, "sconf_norm2_fwd: d=%ld must be a multiple of 4 and <= 768", (long)d);
+    SCONF_REQUIRE(M < (1L << 31), "sconf_norm2_fwd: too many rows");
+    if (M == 0) return 0;
+    NIT_DISPATCH1(launch_norm2_fwd, x, w1, b1, w2, b2, y1, (bf16*)h2_bf16, mean1, rstd1, mean2, rstd2, (int)M, (int)d, eps1, eps2, stream);
+    SCONF_LAUNCH_OK("sconf_norm2_fwd");
+    return 0;
+}
+
+// dx = d(LN1)/dx . (dres + d(LN2)/dy1 . dh2);  dw1/db1/dw2/db2 ACCUMULATED;  dx_bf16 / dx_colsum (both or neither): a bf16 copy of dx and
+// its column sums (overwritten).  workspace: sconf_norm2_bwd_workspace(M, d) floats (required).
+SCONF_API int64_t sconf_norm2_bwd_workspace(int64_t M, int64_t d) { return (int64_t)min(cdiv(M, NBW), bwd_maxgrid()) * 5 * d; }
+SCONF_API int sconf_norm2_bwd(const void* dh2_bf16, const float* x, const float* w1, const float* b1, const float* w2,
+                              const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, const float* dres,
+                              float* dx, float* dw1, float* db1, float* dw2, float* db2, float* workspace, int64_t workspace_floats,
+                              void* dx_bf16, float* dx_colsum, int64_t M, int64_t d, hipStream_t stream) {
+    SCONF_REQUIRE(d % 4 == 0 && d <= 768 && d > 0, "sconf_norm2_bwd: d=%ld must be a multiple of 4 and <= 768", (long)d);
+    SCONF_REQUIRE(M < (1L << 31), "sconf_norm2_bwd: too many rows");
+    SCONF_REQUIRE((dx_bf16 == nullptr) == (dx_colsum == nullptr), "sconf_norm2_bwd: dx_bf16 and dx_colsum go together");
+    if (M == 0) return 0;
+    const int grid = min(cdiv(M, NBW), bwd_maxgrid());
+    SCONF_REQUIRE(workspace && workspace_floats >= (int64_t)grid * 5 * d, "sconf_norm2_bwd: workspace of sconf_norm2_bwd_workspace(M, d) floats required");
+    NIT_DISPATCH1(launch_norm2_bwd, (const bf16*)dh2_bf16, x, w1, b1, w2, mean1, rstd1, mean2, rstd2, dres, dx, workspace, (bf16*)dx_bf16, grid, (int)M, (int)d, stream);
+    Norm2Outs outs = {{dw1, db1, dw2, db2, dx_colsum}};
+    hipLaunchKernelGGL(norm2_bwd_reduce_kernel, dim3(cdiv(5 * d, 64)), dim3(1024), 0, stream, workspace, outs, grid, (int)d);
+    SCONF_LAUNCH_OK("sconf_norm2_bwd");
     return 0;
 }

@@ -14,6 +14,8 @@ Parameters stay f32 masters in the reference's ``state_dict`` layout; a bf16 cop
 """
 from __future__ import annotations
 
+import os
+
 from typing import Optional
 
 import torch
@@ -271,6 +273,46 @@ def norm(x, weight, bias, mode='layer_norm', eps=1e-5, out_dtype=F32):
 
 
 # =================================================================================================
+# norm_out followed by the decoder norm of the self-conditioning step — sconformer_xl.py:371 then 241-243, decoder.py:23
+# =================================================================================================
+class Norm2Fn(Function):
+    """(y1, h2) = (LN(x; w1, b1) f32, LN(y1; w2, b2) bf16) in one pass; the backward takes both gradients at once, so the gradient
+    of y1 the second norm contributes never exists in memory (16 instead of 28 bytes per element; forward 10 instead of 14)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, eps1: float, eps2: float):
+        x = x.contiguous()
+        y1, h2, st = ops.norm2_fwd(x, w1, b1, w2, b2, eps1, eps2)
+        ctx.save_for_backward(x, w1, b1, w2, *st)
+        ctx.P, ctx.eps1 = (w1, b1, w2, b2), eps1
+        return y1, h2
+
+    @staticmethod
+    def backward(ctx, dy1, dh2):
+        x, w1, b1, w2, m1, r1, m2, r2 = ctx.saved_tensors
+        pw1, pb1, pw2, pb2 = ctx.P
+        dw1, db1 = _G(pw1), _G(pb1)
+        if dh2 is None:                                   # h2 was not used: this is norm_out alone
+            dx, dx16, cs = ops.norm_bwd(dy1.contiguous(), x, w1, m1, r1, 'layer_norm', ctx.eps1, None, F32, dw1.t, db1.t, twin=True)
+            _park_twin(dx, dx16, cs)
+            return dx, dw1.out(), db1.out(), None, None, None, None
+        dw2, db2 = _G(pw2), _G(pb2)
+        dx, dx16, cs = ops.norm2_bwd(dh2.contiguous(), x, w1, b1, w2, (m1, r1, m2, r2), None if dy1 is None else dy1.contiguous(),
+                                     dw1.t, db1.t, dw2.t, db2.t, twin=True)
+        _park_twin(dx, dx16, cs)                          # the layer's last block (ff2) receives dx as its output gradient
+        return dx, dw1.out(), db1.out(), dw2.out(), db2.out(), None, None
+
+
+def norm2_enabled(d: int, *modes) -> bool:
+    """The fused pair exists for LayerNorm rows of at most 768 elements (SCONF_NORM2=0 switches it off: A/B, tests)."""
+    return d % 4 == 0 and d <= 768 and all(m == 'layer_norm' for m in modes) and os.environ.get('SCONF_NORM2', '1') != '0'
+
+
+def norm2(x, w1, b1, w2, b2, eps1=1e-5, eps2=1e-5):
+    return Norm2Fn.apply(x, w1, b1, w2, b2, eps1, eps2)
+
+
+# =================================================================================================
 # x + scale * FusedMLP(norm(x))  — Scale(0.5, PreNorm(FusedMLP)); fused_dense.py:425-498, wrappers.py:5-28
 # =================================================================================================
 class FFBlockFn(Function):
@@ -451,9 +493,12 @@ def conv_block(x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, runn
 # =================================================================================================
 class SelfCondFn(Function):
     @staticmethod
-    def forward(ctx, x, nw, nb, wff, bff, wre, bre, has_norm: bool, mode: str, eps: float):
+    def forward(ctx, x, hn_pre, nw, nb, wff, bff, wre, bre, has_norm: bool, mode: str, eps: float):
+        """hn_pre (bf16, optional): norm(x) already computed by the producer of x (Norm2Fn) - its gradient is returned to it."""
         x = x.contiguous()
-        if has_norm:
+        if hn_pre is not None:
+            hn, mean, rstd = hn_pre.contiguous(), None, None
+        elif has_norm:
             hn, mean, rstd = ops.norm_fwd(x, nw, nb, mode, eps, BF16)
         else:
             hn, mean, rstd = ops.cast(x, BF16), None, None
@@ -462,13 +507,13 @@ class SelfCondFn(Function):
         p = ops.softmax_fwd(logits, False, BF16)
         y = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32)
         ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wff), wcast_t(wre), bff, bre, hn, p)
-        ctx.cfg = (has_norm, mode, eps)
+        ctx.cfg = (has_norm, mode, eps, hn_pre is not None)
         ctx.P = (nw, nb, wff, bff, wre, bre)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        has_norm, mode, eps = ctx.cfg
+        has_norm, mode, eps, pre = ctx.cfg
         pnw, pnb, pwf, pbf, pwr, pbr = ctx.P
         x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p = ctx.saved_tensors
         dy = dy.contiguous()
@@ -481,16 +526,18 @@ class SelfCondFn(Function):
         dwf = _wgrad(dl, hn, pwf)
         dbf = gbf.out()
         dhn = ops.gemm(dl, wft, 'nt')
+        if pre:                                                                        # the producer's backward applies both norms
+            return dy, dhn, None, None, dwf, dbf, dwr, dbr, None, None, None
         if has_norm:
             dnw, dnb = _G(pnw), _G(pnb)
             dx = _norm_bwd_res(dhn, x, nw, mean, rstd, mode, eps, dy, dnw.t, dnb.t, twin=False)
-            return dx, dnw.out(), dnb.out(), dwf, dbf, dwr, dbr, None, None, None
+            return dx, None, dnw.out(), dnb.out(), dwf, dbf, dwr, dbr, None, None, None
         dx = dy + ops.cast(dhn, F32)
-        return dx, None, None, dwf, dbf, dwr, dbr, None, None, None
+        return dx, None, None, None, dwf, dbf, dwr, dbr, None, None, None
 
 
-def selfcond_block(x, nw, nb, wff, bff, wre, bre, has_norm=True, mode='layer_norm', eps=1e-5):
-    return SelfCondFn.apply(x, nw, nb, wff, bff, wre, bre, has_norm, mode, eps)
+def selfcond_block(x, nw, nb, wff, bff, wre, bre, has_norm=True, mode='layer_norm', eps=1e-5, prenormed=None):
+    return SelfCondFn.apply(x, prenormed, nw, nb, wff, bff, wre, bre, has_norm, mode, eps)
 
 
 # =================================================================================================

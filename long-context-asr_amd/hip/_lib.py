@@ -20,6 +20,8 @@ PROTOTYPES = {
     'sconf_splitk_reduce': [vp, vp, i64, i64, i32, vp],
     'sconf_norm_fwd': [i32, vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, f32, vp],
     'sconf_norm_bwd': [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i64, f32, vp],
+    'sconf_norm2_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp],
+    'sconf_norm2_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i64, vp],
     'sconf_cast': [vp, i32, vp, i32, i64, vp],
     'sconf_cast_transpose': [vp, vp, i64, i64, vp],
     'sconf_cast_shadows': [vp, i64, i64, vp],
@@ -51,7 +53,7 @@ PROTOTYPES = {
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp, vp],
     'sconf_madgrad_advance': [vp, vp, f32, vp],
 }
-PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
+PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_norm2_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 
 
 def load():

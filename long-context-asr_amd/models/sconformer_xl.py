@@ -107,12 +107,23 @@ class SCConformerXL(BaseModel):
         lengths_dev = None if max(len_host) == min(len_host) else length.to(device=dev, dtype=torch.int32).contiguous()
 
         for lth, layer in enumerate(self.layers):
+            sc = lth != len(self.layers) - 1 and self.self_conditioning
+            # the decoder norm of the self-conditioning step is applied by the layer together with its norm_out (one pass)
+            post = dec.post_norm_spec(x.shape[-1], layer.norm_out.mode) if sc else None
+            h = None
             if self.checkpoint_every_n_layers > 0 and lth % self.checkpoint_every_n_layers == 0:
-                x = checkpoint(layer, x, lengths_dev, rotary, use_reentrant=False)
+                if post is None:
+                    x = checkpoint(layer, x, lengths_dev, rotary, use_reentrant=False)
+                else:                                     # both results are outputs of the checkpointed region
+                    def run(x_, lengths_, rotary_, layer=layer, post=post):
+                        spec = dict(post)
+                        return layer(x_, lengths_, rotary_, post_norm=spec), spec['h']
+                    x, h = checkpoint(run, x, lengths_dev, rotary, use_reentrant=False)
             else:
-                x = layer(x, lengths_dev, rotary)
-            if lth != len(self.layers) - 1 and self.self_conditioning:
-                x = dec.self_condition(x)
+                x = layer(x, lengths_dev, rotary, post_norm=post)
+                h = None if post is None else post.get('h')
+            if sc:
+                x = dec.self_condition(x, prenormed=h)
         final = dec(x, logits=return_logits, extra_norms=1 if self.legasee_double_norm else 0)
         if self.training and self.rotary_pos_emb is not None:
             self.rotary_pos_emb.reset_if_needed()
@@ -142,11 +153,19 @@ class ConformerLayer(nn.Module):
         self.do_attn_out = nn.Dropout(min(dropout_ff, 0.1))
         self.norm_out = default_norm(d_model)
 
-    def forward(self, x, lengths=None, rotary=None):
+    def forward(self, x, lengths=None, rotary=None, post_norm=None):
         """sconformer_xl.py:346-372 with every branch fused with its residual add.
-        x (B,N,d) f32; lengths int32 (B,) on device when the batch is ragged, else None; rotary = (cos, sin) tables."""
+        x (B,N,d) f32; lengths int32 (B,) on device when the batch is ragged, else None; rotary = (cos, sin) tables.
+        post_norm (optional, ASRLinearSCDecoder.post_norm_spec): the LayerNorm the consumer of this layer's output applies first;
+        it is computed in the same pass as norm_out and left in post_norm['h'] (bf16)."""
         x = self.ff1(x, residual=True)
         x = self.attend(x, residual=True, lengths=lengths, rotary=rotary)
         x = self.conv(x, residual=True, lengths=lengths)
         x = self.ff2(x, residual=True)
+        if post_norm is not None:
+            nw, nb = self.norm_out.norm_params()
+            shape = x.shape
+            y, h = Fn.norm2(x.reshape(-1, shape[-1]), nw, nb, post_norm['w'], post_norm['b'], self.norm_out.eps, post_norm['eps'])
+            post_norm['h'] = h.view(shape)
+            return y.view(shape)
         return self.norm_out(x)

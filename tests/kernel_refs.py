@@ -105,6 +105,19 @@ def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbia
     return dx.to(dx_dtype)
 
 
+def norm2_fwd(x, w1, b1, w2, b2, eps1, eps2):
+    y1, m1, r1 = norm_fwd(x, w1, b1, 'layer_norm', eps1, f32)
+    h2, m2, r2 = norm_fwd(y1, w2, b2, 'layer_norm', eps2, torch.bfloat16)
+    return y1, h2, (m1, r1, m2, r2)
+
+
+def norm2_bwd(dh2, x, w1, b1, w2, stats, dres, dw1, db1, dw2, db2, twin=False):
+    m1, r1, m2, r2 = stats
+    y1 = ((x.to(f32) - m1.view(-1, 1)) * r1.view(-1, 1)).view(x.shape) * w1 + b1
+    dy1 = norm_bwd(dh2, y1, w2, m2, r2, 'layer_norm', 0.0, dres, f32, dw2, db2)
+    return norm_bwd(dy1, x, w1, m1, r1, 'layer_norm', 0.0, None, f32, dw1, db1, twin=twin)
+
+
 def cast(x, dtype): return x.to(dtype)
 
 
