@@ -163,6 +163,20 @@ int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t*
 int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const float* nll,
                   const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths, const float* grad_out,
                   float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
+/* The same loss taken from the decoder's LOGITS (f32 (B,N,C)): decoder.py:25 F.log_softmax + torch.nn.CTCLoss (exp/train.py:104,249)
+ * as one operator.  The forward folds log_softmax into the emission gather and keeps the row log-sum-exp (lse, f32 (B,N)); the
+ * backward returns d nll / d logits in bf16 (the CTC gradient through log_softmax) and, optionally, its column sums ACCUMULATED
+ * into colsum_out [C] (the decoder bias gradient; needs sconf_ctc_bwd_logits_workspace(B*N, C) floats of scratch).  Neither the
+ * log-probabilities nor their gradient exist as (B,N,C) tensors. */
+int sconf_ctc_fwd_logits(const float* logits, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
+                         float* lse, float* lpg, float* alpha, float* beta, float* nll,
+                         int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
+int64_t sconf_ctc_bwd_logits_workspace(int64_t rows, int64_t C);
+int sconf_ctc_bwd_logits(const float* logits, const float* lse, const float* lpg, const float* alpha, const float* beta,
+                         const float* nll, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
+                         const float* grad_out, void* dlogits_bf16, float* colsum_out, float* workspace,
+                         int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
+
 
 /* ---- forward-only inference helpers ------------------------------------------------------------------
  * Overlap-average of sliding-window posteriors, fetch_logits (lcasr/eval/utils.py:45-111): for W equally long windows

@@ -30,6 +30,16 @@ class ASRLinearSCDecoder(nn.Module):
         y = Fn.decoder_head(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, n_norms, mode, eps, logits)
         return y.view(*shape[:-1], self.num_classes)
 
+    def ctc_nll(self, x, targets, input_lengths, target_lengths, extra_norms=0):
+        """CTCLoss(blank = vocab_size, reduction='none')(log_softmax(ff(norm(x)))) as ONE operator (Fn.HeadCTCFn): (B,) negative
+        log-likelihoods; the (B,N,V+1) log-probabilities and their gradient are never materialised."""
+        shape = x.shape
+        nw, nb = self._np()
+        n_norms = (1 + extra_norms) if self.has_norm else 0
+        mode, eps = (self.norm.mode, self.norm.eps) if self.has_norm else ('layer_norm', 1e-5)
+        return Fn.decoder_head_ctc(x.reshape(-1, shape[-1]), nw, nb, self.ff.weight, self.ff.bias, shape[0], targets, input_lengths,
+                                   target_lengths, self.num_classes - 1, n_norms, mode, eps)
+
     def post_norm_spec(self, d_model, producer_mode):
         """What a layer needs to apply this decoder's norm together with its own `norm_out` (Fn.norm2): a dict the layer fills with
         'h' = norm(layer output) in bf16, or None when the pair cannot be fused (no norm, not LayerNorm, rows wider than 768)."""

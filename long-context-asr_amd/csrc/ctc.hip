@@ -11,6 +11,7 @@
 //               grad = g * (exp(lp) - occupancy)   [ATen convention; zero for t >= input_length].
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 
 namespace {
 
@@ -26,28 +27,48 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
 // One workgroup per (sample, frame): the frame's whole log-prob row is streamed into LDS with 16-byte loads and the 2S+1 lattice
 // emissions are gathered from there (a thread-per-emission gather from global memory touched every 64-byte sector of the row
 // for 4 useful bytes each: 1.68 ms at B = 128, N = 2048, C = 4096 against 0.9 ms for row + lattice bytes at the HBM rate).
+// LOGITS: `lp` holds raw logits; the row's log-sum-exp is computed from the LDS copy, written to lse[b][t], and the emissions are
+// logit - lse - the log_softmax pass (and its (B,N,C) output) is then not needed for the loss (sconf_ctc_fwd_logits).
+template <bool LOGITS>
 __global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict__ lp, const int* __restrict__ targets, const int* __restrict__ in_len,
-                                                         const int* __restrict__ tg_len, float* __restrict__ lpg, int B, int N, int C, int Smax,
-                                                         int Lmax, int blank) {
+                                                         const int* __restrict__ tg_len, float* __restrict__ lpg, float* __restrict__ lse_out,
+                                                         int B, int N, int C, int Smax, int Lmax, int blank) {
     extern __shared__ float row[];                      // [C]
+    __shared__ float red[16];
     for (long bt = blockIdx.x; bt < (long)B * N; bt += gridDim.x) {
         const int t = (int)(bt % N), b = (int)(bt / N);
         float* out = lpg + bt * Lmax;
         const int L = 2 * tg_len[b] + 1;
         if (t >= in_len[b]) {                           // frames past the sample's length: zeros (never read by the lattice)
             for (int s = threadIdx.x; s < Lmax; s += 256) out[s] = 0.f;
+            if (LOGITS && threadIdx.x == 0) lse_out[bt] = 0.f;
             continue;
         }
         __syncthreads();                                // the previous row's gathers are done
         const float* src = lp + bt * C;
-        for (int c = threadIdx.x * 4; c < C; c += 1024) *reinterpret_cast<float4*>(row + c) = *reinterpret_cast<const float4*>(src + c);
-        __syncthreads();
+        float mx = -INFINITY;
+        for (int c = threadIdx.x * 4; c < C; c += 1024) {
+            const float4 v = *reinterpret_cast<const float4*>(src + c);
+            *reinterpret_cast<float4*>(row + c) = v;
+            if (LOGITS) mx = fmaxf(mx, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+        float lse = 0.f;
+        if (LOGITS) {
+            mx = block_max(mx, red);                    // (its barriers also publish the row)
+            float sm = 0.f;
+            for (int c = threadIdx.x * 4; c < C; c += 1024) {
+                const float4 v = *reinterpret_cast<const float4*>(row + c);
+                sm += __expf(v.x - mx) + __expf(v.y - mx) + __expf(v.z - mx) + __expf(v.w - mx);
+            }
+            lse = mx + __logf(block_sum(sm, red));
+            if (threadIdx.x == 0) lse_out[bt] = lse;
+        } else __syncthreads();
         for (int s = threadIdx.x; s < Lmax; s += 256) {
             float v = 0.f;
             if (s < L) {
                 int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
                 lab = min(max(lab, 0), C - 1);          // an out-of-range label poisons the sample (alpha/beta kernel); never index with it
-                v = row[lab];
+                v = row[lab] - lse;
             }
             out[s] = v;
         }
@@ -184,33 +205,168 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     }
 }
 
+// Gradient with respect to the LOGITS in one pass (the CTC gradient followed by the log_softmax backward):
+//   dlogit[c] = g (softmax[c] S - occupancy[c]),   S = sum_c occupancy[c]   (= 1 up to rounding for a feasible alignment)
+// [ATen: dlogp = g (exp(lp) - occ); log_softmax backward: dlogit = dlogp - exp(lp) sum_c dlogp, and sum_c dlogp = g (1 - S)].
+// bf16 output (the operand of the decoder's dgrad / wgrad GEMMs); `slab` (optional, [gridDim.x][C] f32): the workgroup's column sums
+// of what it stored - the decoder bias gradient.  A workgroup walks rows_per_block consecutive (b, t) rows.
+__global__ __launch_bounds__(256) void ctc_grad_logits_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
+                                                              const float* __restrict__ lpg, const float* __restrict__ alpha,
+                                                              const float* __restrict__ beta, const float* __restrict__ nll,
+                                                              const int* __restrict__ targets, const int* __restrict__ in_len,
+                                                              const int* __restrict__ tg_len, const float* __restrict__ grad_out,
+                                                              bf16* __restrict__ dlogits, float* __restrict__ slab,
+                                                              long rows, int N, int C, int Smax, int Lmax, int blank, int rows_per_block) {
+    extern __shared__ float occ[];                      // [C]
+    __shared__ float ssum;
+    constexpr int MAXIT = 8;                            // C <= 8192
+    float cs[MAXIT][4];
+#pragma unroll
+    for (int k = 0; k < MAXIT; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) cs[k][e] = 0.f;
+    const long r0 = (long)blockIdx.x * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    for (long bt = r0; bt < r1; ++bt) {
+        const int b = (int)(bt / N), t = (int)(bt % N);
+        bf16* out = dlogits + bt * C;
+        const float nl = nll[b];
+        const bool pad = t >= in_len[b], bad = !(nl < INFINITY);          // uniform over the workgroup
+        if (pad || bad) {
+            // padded frames: zero gradient; a sample with no alignment (nll = +inf) or a poisoned one (NaN): NaN rows, as ATen's
+            const float f = pad ? 0.f : NAN;
+#pragma unroll
+            for (int k = 0; k < MAXIT; ++k) {
+                const int c = k * 1024 + threadIdx.x * 4;
+                if (c < C) {
+                    float v[4] = {f, f, f, f};
+                    store4(out + c, v);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) cs[k][e] += f;
+                }
+            }
+            continue;
+        }
+        // this row's logits are requested first: their latency runs under the occupancy phase (which waits on its own loads)
+        const float* lr = logits + bt * C;
+        float4 lv[MAXIT];
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            const int c = k * 1024 + threadIdx.x * 4;
+            if (c < C) lv[k] = *reinterpret_cast<const float4*>(lr + c);
+        }
+        __syncthreads();                                // the previous row's reads of occ / ssum are done
+        for (int c = threadIdx.x; c < C; c += 256) occ[c] = 0.f;
+        if (threadIdx.x == 0) ssum = 0.f;
+        __syncthreads();
+        const int L = 2 * tg_len[b] + 1;
+        const long base = bt * Lmax;
+        // Half of the states are the blank: as LDS atomics they would all hit ONE address (a 32-way conflict per wave
+        // instruction).  The stride (256) is even, so a thread sees either blanks only or labels only: blanks are summed in
+        // registers, then per wave (no barrier), and added with one atomic per wave - as is S, the sum of all occupancies.
+        float tot = 0.f, blk = 0.f;
+        for (int s = threadIdx.x; s < L; s += 256) {
+            const float o = __expf(alpha[base + s] + beta[base + s] + nl - lpg[base + s]);
+            if (s & 1) atomicAdd(&occ[targets[(long)b * Smax + (s >> 1)]], o); else blk += o;
+            tot += o;
+        }
+        tot = wave_sum(tot); blk = wave_sum(blk);
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&ssum, tot); atomicAdd(&occ[blank], blk); }
+        __syncthreads();                                // occ and ssum are complete
+        const float S = ssum;
+        const float g = grad_out ? grad_out[b] : 1.f, ls = lse[bt];
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            const int c = k * 1024 + threadIdx.x * 4;
+            if (c < C) {
+                float v[4] = {lv[k].x, lv[k].y, lv[k].z, lv[k].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v[e] = g * (__expf(v[e] - ls) * S - occ[c + e]); cs[k][e] += (float)(bf16)v[e]; }
+                store4(out + c, v);
+            }
+        }
+    }
+    if (slab) {
+#pragma unroll
+        for (int k = 0; k < MAXIT; ++k) {
+            const int c = k * 1024 + threadIdx.x * 4;
+            if (c < C) store4(slab + (long)blockIdx.x * C + c, cs[k]);
+        }
+    }
+}
+
 }  // namespace
+
+SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, hipStream_t stream);
 
 // Workspace contract: lpg, alpha, beta are f32 [B][N][Lmax] with Lmax = 2*Smax+1 (caller-allocated).
 // targets int32 [B][Smax]; input_lengths / target_lengths int32 [B].  nll f32 [B] (loss = sum).
-SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
-                            const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
-                            int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
+static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, float* lse, const int32_t* targets, const int32_t* input_lengths,
+                        const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
+                        int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
     if (B == 0) return 0;
     const int Lmax = (int)(2 * Smax + 1);
-    SCONF_REQUIRE(blank >= 0 && blank < C, "sconf_ctc_fwd: blank %d out of range", blank);
-    SCONF_REQUIRE((long)(Lmax + 2) * 8 <= 160 * 1024, "sconf_ctc_fwd: lattice of %d states does not fit LDS", Lmax);
-    const long total = B * N * Lmax;
-    SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "sconf_ctc_fwd: C must be a multiple of 4 and one row must fit LDS (%ld classes)", (long)C);
-    hipLaunchKernelGGL(ctc_gather_kernel, dim3((unsigned)std::min<long>(B * N, 65536)), dim3(256), (size_t)C * 4, stream,
-                       log_probs, targets, input_lengths, target_lengths, lpg, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
+    SCONF_REQUIRE(blank >= 0 && blank < C, "%s: blank %d out of range", who, blank);
+    SCONF_REQUIRE((long)(Lmax + 2) * 8 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);
+    SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "%s: C must be a multiple of 4 and one row must fit LDS (%ld classes)", who, (long)C);
+    const dim3 gg((unsigned)std::min<long>(B * N, 65536));
+    if (from_logits) hipLaunchKernelGGL(ctc_gather_kernel<true>, gg, dim3(256), (size_t)C * 4, stream, in, targets, input_lengths, target_lengths,
+                                        lpg, lse, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
+    else hipLaunchKernelGGL(ctc_gather_kernel<false>, gg, dim3(256), (size_t)C * 4, stream, in, targets, input_lengths, target_lengths,
+                            lpg, (float*)nullptr, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
     const size_t sh = (size_t)2 * (Lmax + 2) * sizeof(float);
-    SCONF_REQUIRE(spt <= 16, "sconf_ctc_fwd: target too long (%ld labels)", (long)Smax);
+    SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
 #define L(MS) do { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((ctc_alphabeta_kernel<MS>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
                            target_lengths, alpha, beta, nll, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
     if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
 #undef L
+    return 0;
+}
+
+SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
+                            const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
+                            int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
+    if (ctc_fwd_impl("sconf_ctc_fwd", false, log_probs, nullptr, targets, input_lengths, target_lengths, lpg, alpha, beta, nll, B, N, C, Smax, blank, stream)) return 1;
     SCONF_LAUNCH_OK("sconf_ctc_fwd");
+    return 0;
+}
+
+// The same loss from the decoder's LOGITS (f32 (B,N,C)): log_softmax is folded into the emission gather (row log-sum-exp -> lse
+// (B,N) f32, kept for the backward), so neither the log-probabilities nor their gradient exist as (B,N,C) tensors:
+// decoder.py:25 F.log_softmax + exp/train.py:104,249 CTCLoss as one operator.
+SCONF_API int sconf_ctc_fwd_logits(const float* logits, const int32_t* targets, const int32_t* input_lengths,
+                                   const int32_t* target_lengths, float* lse, float* lpg, float* alpha, float* beta, float* nll,
+                                   int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
+    if (ctc_fwd_impl("sconf_ctc_fwd_logits", true, logits, lse, targets, input_lengths, target_lengths, lpg, alpha, beta, nll, B, N, C, Smax, blank, stream)) return 1;
+    SCONF_LAUNCH_OK("sconf_ctc_fwd_logits");
+    return 0;
+}
+
+constexpr int CTC_BWD_SLABS = 2048;
+SCONF_API int64_t sconf_ctc_bwd_logits_workspace(int64_t rows, int64_t C) { return (int64_t)std::min<long>(rows, CTC_BWD_SLABS) * C; }
+// dlogits (B,N,C) bf16 = d nll / d logits (CTC gradient through log_softmax), scaled by grad_out[b] (null = 1).
+// colsum_out (optional, f32 [C], ACCUMULATED): column sums of dlogits - the decoder bias gradient; needs the workspace
+// (sconf_ctc_bwd_logits_workspace(B * N, C) floats).
+SCONF_API int sconf_ctc_bwd_logits(const float* logits, const float* lse, const float* lpg, const float* alpha, const float* beta,
+                                   const float* nll, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
+                                   const float* grad_out, void* dlogits_bf16, float* colsum_out, float* workspace,
+                                   int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
+    if (B * N == 0) return 0;
+    SCONF_REQUIRE(C % 4 == 0 && C <= 8192, "sconf_ctc_bwd_logits: C must be a multiple of 4 and <= 8192");
+    SCONF_REQUIRE(!colsum_out || workspace, "sconf_ctc_bwd_logits: colsum_out needs the workspace");
+    const int Lmax = (int)(2 * Smax + 1);
+    const long rows = B * N;
+    const int rpb = colsum_out ? (int)cdiv(rows, CTC_BWD_SLABS) : 1;
+    const unsigned grid = (unsigned)cdiv(rows, rpb);
+    hipLaunchKernelGGL(ctc_grad_logits_kernel, dim3(grid), dim3(256), (size_t)C * 4, stream, logits, lse, lpg, alpha, beta, nll, targets,
+                       input_lengths, target_lengths, grad_out, (bf16*)dlogits_bf16, colsum_out ? workspace : nullptr, rows, (int)N, (int)C,
+                       (int)Smax, Lmax, blank, rpb);
+    SCONF_LAUNCH_OK("sconf_ctc_bwd_logits");
+    if (colsum_out) return sconf_colsum(workspace, SCONF_F32, colsum_out, (int64_t)grid, C, C, 1.f, stream);     // += over the slabs
     return 0;
 }
 

@@ -46,6 +46,8 @@ PROTOTYPES = {
     'sconf_sub_silu_transpose': [i32, vp, vp, vp, i64, i64, i64, vp],
     'sconf_ctc_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_ctc_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_fwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_bwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_overlap_add_exp': [vp, i64, i64, i64, i64, i64, vp, vp, i64, vp],
     'sconf_overlap_finalize': [vp, vp, vp, i64, i64, vp],
     'sconf_argmax_rows': [vp, i64, i64, vp, vp],
@@ -53,7 +55,7 @@ PROTOTYPES = {
     'sconf_madgrad_step': [vp, vp, vp, vp, vp, vp, i64, vp, f32, f32, f32, f32, f32, f32, i64, vp, vp],
     'sconf_madgrad_advance': [vp, vp, f32, vp],
 }
-PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_norm2_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
+PLAIN = {'sconf_softmax_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_gemm_variant': ([i32, i64, i64, i64, i64, i64, i32, i32, i32, i32], C.c_int), 'sconf_norm_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_norm2_bwd_workspace': ([i64, i64], C.c_int64), 'sconf_ctc_bwd_logits_workspace': ([i64, i64], C.c_int64), 'sconf_version': ([], C.c_int), 'sconf_num_cus': ([], C.c_int), 'sconf_last_error': ([], C.c_char_p)}
 
 
 def load():

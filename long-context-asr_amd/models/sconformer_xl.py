@@ -82,9 +82,13 @@ class SCConformerXL(BaseModel):
                                               default_norm=norm_cls, sandwich_norm=sandwich_norm, bias_in_ff=bias_in_ff,
                                               transformer=transformer, conv_expansion_factor=conv_expansion_factor, **kwargs))
 
-    def forward(self, audio_signal, length=None, cached_kvs=None, cached_kv_lengths=None, return_logits=False):
+    def forward(self, audio_signal, length=None, cached_kvs=None, cached_kv_lengths=None, return_logits=False, ctc_targets=None):
         """audio_signal: (B, feat_in, T) f32/bf16 on the GPU; length: (B,) ints or None.
-        Returns {'final_posteriors': (B, N, V+1) f32 log-probs (logits if return_logits), 'length': (B,) int32}."""
+        Returns {'final_posteriors': (B, N, V+1) f32 log-probs (logits if return_logits), 'length': (B,) int32}.
+        ctc_targets = (targets (B, S), target_lengths (B,)) (an extension of the reference signature, used by the training step):
+        the head and the CTC loss run as one operator and the dict holds 'ctc_nll' (B,) - what
+        CTCLoss(blank=vocab_size, reduction='none')(final_posteriors.transpose(0, 1), targets, length, target_lengths) would give -
+        instead of the posteriors, which are then never written ('final_posteriors' is None)."""
         if cached_kvs is not None:
             raise NotImplementedError('cached_kvs is vestigial in the reference (SURVEY.md fact 8) and not supported')
         Fn.ops.require_gpu(audio_signal, 'audio_signal')
@@ -124,10 +128,14 @@ class SCConformerXL(BaseModel):
                 h = None if post is None else post.get('h')
             if sc:
                 x = dec.self_condition(x, prenormed=h)
-        final = dec(x, logits=return_logits, extra_norms=1 if self.legasee_double_norm else 0)
+        extra = 1 if self.legasee_double_norm else 0
+        if ctc_targets is not None:
+            out = {'final_posteriors': None, 'length': length, 'ctc_nll': dec.ctc_nll(x, ctc_targets[0], length, ctc_targets[1], extra_norms=extra)}
+        else:
+            out = {'final_posteriors': dec(x, logits=return_logits, extra_norms=extra), 'length': length}
         if self.training and self.rotary_pos_emb is not None:
             self.rotary_pos_emb.reset_if_needed()
-        return {'final_posteriors': final, 'length': length}
+        return out
 
 
 class ConformerLayer(nn.Module):

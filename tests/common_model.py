@@ -14,20 +14,25 @@ def build_from_fixture(fx, device='cpu'):
     return m.to(device).train()
 
 
-def run_step(m, fx, device='cpu'):
-    """forward + CTC(sum) + the reference loss scaling (exp/train.py:275) + backward.  Returns a dict of CPU results."""
+def run_step(m, fx, device='cpu', fused_loss=False):
+    """forward + CTC(sum) + the reference loss scaling (exp/train.py:275) + backward.  Returns a dict of CPU results.
+    fused_loss: the head and the loss as one operator (model(..., ctc_targets=...)); no log-probabilities then ('logp' is None)."""
     from lcasr_amd.losses import CTCLoss
     x = torch.from_numpy(fx['x']).to(device)
     ln = torch.from_numpy(fx['lengths']).to(device)
-    out = m(x, length=ln)
-    lp = out['final_posteriors']
     B, _, T = x.shape
-    loss = CTCLoss(blank=m.decoder.num_classes - 1, reduction='sum')(
-        lp.transpose(0, 1), torch.from_numpy(fx['targets']).to(device), out['length'], torch.from_numpy(fx['target_lengths']).to(device))
+    tg, tl = torch.from_numpy(fx['targets']).to(device), torch.from_numpy(fx['target_lengths']).to(device)
+    if fused_loss:
+        out = m(x, length=ln, ctc_targets=(tg, tl))
+        lp, loss = None, out['ctc_nll'].sum()
+    else:
+        out = m(x, length=ln)
+        lp = out['final_posteriors']
+        loss = CTCLoss(blank=m.decoder.num_classes - 1, reduction='sum')(lp.transpose(0, 1), tg, out['length'], tl)
     (loss / (T * B) * 100).backward()
     if device != 'cpu':
         torch.cuda.synchronize()
-    return dict(logp=lp.detach().float().cpu(), length=out['length'].cpu(), loss=float(loss),
+    return dict(logp=None if lp is None else lp.detach().float().cpu(), length=out['length'].cpu(), loss=float(loss),
                 grads={k: p.grad.detach().float().cpu() for k, p in m.named_parameters()},
                 buffers={k: v.detach().float().cpu() for k, v in m.state_dict().items() if 'batch_norm.running' in k or 'num_batches' in k})
 

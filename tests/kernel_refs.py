@@ -423,6 +423,22 @@ def ctc_bwd(log_probs, ws, nll, targets, input_lengths, target_lengths, grad_out
     return lp.grad
 
 
+def ctc_fwd_logits(logits, targets, input_lengths, target_lengths, blank):
+    nll, _ = ctc_fwd(torch.log_softmax(logits.to(f32), -1), targets, input_lengths, target_lengths, blank)
+    return nll, (None, None, None, None)
+
+
+def ctc_bwd_logits(logits, ws, nll, targets, input_lengths, target_lengths, grad_out, blank, colsum_into=None):
+    lg = logits.detach().to(f32).clone().requires_grad_(True)
+    with torch.enable_grad():
+        nll_ = F.ctc_loss(torch.log_softmax(lg, -1).transpose(0, 1), targets.long(), input_lengths.long(), target_lengths.long(),
+                          blank=blank, reduction='none', zero_infinity=False)
+        nll_.backward(grad_out if grad_out is not None else torch.ones_like(nll_))
+    dl = lg.grad.to(torch.bfloat16)
+    if colsum_into is not None: colsum_into += dl.to(f32).reshape(-1, dl.shape[-1]).sum(0)
+    return dl
+
+
 def sumsq_(g, out):
     out += (g.double() ** 2).sum()
     return out

@@ -53,6 +53,23 @@ def test_wiring_against_reference_fixture(emulated_ops, case):
             assert float((got - torch.from_numpy(fx[k]).float()).abs().max()) < 2e-3, k
 
 
+@pytest.mark.parametrize('case', ['tiny_ln_ragged', 'tiny_rms_ragged', 'tiny_ln_ckpt'])
+def test_fused_head_ctc_wiring_against_reference_fixture(emulated_ops, case):
+    """model(..., ctc_targets=...): head + log_softmax + CTC as one operator (the training step's path) - same loss and gradients
+    as the reference fixture, and the same as this package's two-call path up to the bf16 rounding of d loss / d logits."""
+    fx = load_golden(case)
+    m = build_from_fixture(fx)
+    r = run_step(m, fx, fused_loss=True)
+    assert r['logp'] is None and torch.equal(r['length'], torch.from_numpy(fx['out_length']))
+    assert abs(r['loss'] - float(fx['loss'])) / float(fx['loss']) < 2e-3
+    errs = rel_l2_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')})
+    assert max(errs.values()) < 0.12 and float(np.median(list(errs.values()))) < 0.05, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    r2 = run_step(build_from_fixture(fx), fx)
+    assert abs(r['loss'] - r2['loss']) / r2['loss'] < 1e-6
+    errs = rel_l2_errors(r['grads'], r2['grads'])
+    assert max(errs.values()) < 0.02, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+
+
 def test_direct_gradient_accumulation_matches_autograd(emulated_ops):
     """The training driver lets the backward kernels accumulate into pre-attached .grad buffers (flat gradient buffer)
     instead of returning gradients to autograd: same gradients; the ready-hook fires once per write (parameters shared by

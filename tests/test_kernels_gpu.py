@@ -554,6 +554,59 @@ def test_ctc_edge_cases(ops):
     assert float(grad[2, 8:].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('B,N,C,S,ragged', [(3, 64, 32, 10, True), (2, 300, 4096, 40, True), (1, 128, 512, 20, False)])
+def test_ctc_from_logits(ops, B, N, C, S, ragged):
+    """log_softmax + CTC as one operator (sconf_ctc_fwd_logits / sconf_ctc_bwd_logits): against the separate operators on the
+    device (log_softmax -> ctc_fwd / ctc_bwd -> log_softmax backward) and against torch on the CPU."""
+    g = torch.Generator().manual_seed(N + C)
+    lg = torch.randn(B, N, C, generator=g) * 2.0
+    tg = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32)
+    tg[0, 1] = tg[0, 0]
+    il = torch.full((B,), N, dtype=torch.int32); tl = torch.full((B,), S, dtype=torch.int32)
+    if ragged:
+        il[1] = N - 17; tl[1] = max(1, S // 3); il[-1] = max(2 * S + 1, N // 2)
+    go = torch.tensor([1.0, 0.5, 2.0][:B])
+    nll, ws = ops.ctc_fwd_logits(dev(lg), dev(tg), dev(il), dev(tl), C - 1)
+    cs = torch.zeros(C, device='cuda')
+    dl = ops.ctc_bwd_logits(dev(lg), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1, colsum_into=cs)
+    assert dl.dtype == BF and dl.shape == (B, N, C)
+    # separate operators on the device
+    lp = ops.softmax_fwd(dev(lg), True, F32)
+    nll2, ws2 = ops.ctc_fwd(lp, dev(tg), dev(il), dev(tl), C - 1)
+    assert float(((nll - nll2) / nll2).abs().max()) < 2e-6, (nll, nll2)
+    cs2 = torch.zeros(C, device='cuda')
+    dl2 = ops.softmax_bwd(lp, ops.ctc_bwd(lp, ws2, nll2, dev(tg), dev(il), dev(tl), dev(go), C - 1), True, BF, colsum_into=cs2)
+    close(dl, dl2.cpu().view(B, N, C), name='fused CTC gradient vs separate operators', floor=1e-3)
+    close(cs, cs2.cpu(), name='fused CTC gradient column sums', tol=2e-3, floor=1e-2)
+    # torch reference
+    nllr, _ = R.ctc_fwd_logits(lg, tg, il, tl, C - 1)
+    assert float(((nll.cpu() - nllr) / nllr).abs().max()) < 1e-4, (nll, nllr)
+    csr = torch.zeros(C)
+    dlr = R.ctc_bwd_logits(lg, None, nllr, tg, il, tl, go, C - 1, colsum_into=csr)
+    close(dl, dlr, name='fused CTC gradient vs torch', tol=1.5e-2, floor=1e-3)
+    close(cs, csr, name='fused CTC column sums vs torch', tol=1e-2, floor=1e-2)
+    if B > 1 and int(il[1]) < N: assert float(dl[1, int(il[1]):].float().abs().max()) == 0.0
+    assert torch.equal(ops.ctc_bwd_logits(dev(lg), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1), dl)     # without the column sums
+
+
+def test_ctc_from_logits_edge_cases(ops):
+    """Infeasible alignment (nll = +inf -> NaN rows inside the sample, zeros behind its length), empty target."""
+    B, N, C, S = 3, 20, 16, 6
+    g = torch.Generator().manual_seed(0)
+    lg = torch.randn(B, N, C, generator=g)
+    tg = torch.randint(0, C - 1, (B, S), generator=g, dtype=torch.int32)
+    tg[2] = 3
+    il = torch.tensor([20, 20, 8], dtype=torch.int32); tl = torch.tensor([6, 0, 6], dtype=torch.int32)
+    nll, ws = ops.ctc_fwd_logits(dev(lg), dev(tg), dev(il), dev(tl), C - 1)
+    nllr, _ = R.ctc_fwd_logits(lg, tg, il, tl, C - 1)
+    n = nll.cpu()
+    assert torch.isinf(n[2]) and n[2] > 0 and float(((n[:2] - nllr[:2]) / nllr[:2]).abs().max()) < 1e-4, (n, nllr)
+    dl = ops.ctc_bwd_logits(dev(lg), ws, nll, dev(tg), dev(il), dev(tl), None, C - 1).float().cpu()
+    dlr = R.ctc_bwd_logits(lg, None, nllr, tg, il, tl, None, C - 1).float()
+    close(dl[:2], dlr[:2], name='fused CTC gradient (feasible samples)', tol=1.5e-2)
+    assert torch.isnan(dl[2, :8]).all() and float(dl[2, 8:].abs().max()) == 0.0
+
+
 def test_empty_row_batches(ops):
     """M = 0 (a recording whose last chunk is empty, a shrunk batch): every row-wise entry point returns without a launch."""
     d = 64

@@ -58,6 +58,26 @@ def _need_gpu():
 
 
 @pytest.mark.parametrize('case', TINY_CASES)
+def test_fused_head_ctc_loss_vs_reference_fixture_and_two_call_path(case):
+    """model(..., ctc_targets=...) - head, log_softmax and CTC as one operator (what Trainer.step runs) - against the reference
+    fixture (loss, every gradient, BatchRenorm buffers) and against this package's own two-call path (posteriors, then CTCLoss)."""
+    fx = load_golden(case)
+    m = build_from_fixture(fx, 'cuda')
+    r = run_step(m, fx, 'cuda', fused_loss=True)
+    assert r['logp'] is None and torch.equal(r['length'], torch.from_numpy(fx['out_length']))
+    assert abs(r['loss'] - float(fx['loss'])) / float(fx['loss']) < 2e-3, (r['loss'], float(fx['loss']))
+    _check_grad_l2(case + ' (fused loss)', rel_l2_errors(r['grads'], {k[2:]: fx[k] for k in fx.files if k.startswith('g.')}), noise_case=case)
+    m2 = build_from_fixture(fx, 'cuda')
+    r2 = run_step(m2, fx, 'cuda')
+    assert abs(r['loss'] - r2['loss']) / r2['loss'] < 2e-6, (r['loss'], r2['loss'])
+    errs = rel_l2_errors(r['grads'], r2['grads'])
+    _report(case + ' fused vs two-call', errs)
+    assert max(errs.values()) < 0.05, sorted(errs.items(), key=lambda kv: -kv[1])[:5]        # same bf16 dlogits up to an ulp (7e-6 at the decoder), amplified through the bf16 backward
+    for k, v in r['buffers'].items():
+        assert torch.equal(v, r2['buffers'][k]), k
+
+
+@pytest.mark.parametrize('case', TINY_CASES)
 def test_tiny_model_vs_reference_fixture(case):
     fx = load_golden(case)
     m = build_from_fixture(fx, 'cuda')
