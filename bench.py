@@ -197,12 +197,19 @@ def cpu_baseline(cfg_name: str):
     from lcasr_amd.losses import CTCLoss
     torch.manual_seed(12345)
     m = SCConformerXL(**cfg['model']).cuda().train()
+    tl = torch.tensor([tg.shape[1]]).cuda()
     with torch.no_grad():
+        # the operator the timed step runs (head + log_softmax + CTC in one) ...
+        hip_loss = float(m(x.cuda(), length=torch.tensor([T]).cuda(), ctc_targets=(tg.cuda(), tl))['ctc_nll'].sum())
+    torch.manual_seed(12345)
+    m = SCConformerXL(**cfg['model']).cuda().train()                 # (fresh BatchRenorm buffers: the forward above moved them)
+    with torch.no_grad():
+        # ... and the reference's two calls (posteriors, then CTCLoss)
         out = m(x.cuda(), length=torch.tensor([T]).cuda())
-        hip_loss = float(CTCLoss(blank=m.decoder.num_classes - 1, reduction='sum')(
-            out['final_posteriors'].transpose(0, 1), tg.cuda(), out['length'], torch.tensor([tg.shape[1]]).cuda()))
+        hip_loss2 = float(CTCLoss(blank=m.decoder.num_classes - 1, reduction='sum')(out['final_posteriors'].transpose(0, 1), tg.cuda(), out['length'], tl))
     res['hip_loss_same_sample'] = round(hip_loss, 3)
-    res['ctc_loss_rel_err'] = float(f'{abs(hip_loss - loss) / abs(loss):.3e}')
+    res['hip_loss_two_call_path'] = round(hip_loss2, 3)
+    res['ctc_loss_rel_err'] = float(f'{max(abs(hip_loss - loss), abs(hip_loss2 - loss)) / abs(loss):.3e}')
     return res
 
 
