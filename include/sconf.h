@@ -66,13 +66,16 @@ int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_
  * takes the gradient of h2 (bf16) and the gradient reaching y1 directly (dres, f32, nullable), recomputes y1 from x and the saved
  * statistics, and ACCUMULATES the four parameter gradients; dx_bf16 / dx_colsum as in sconf_norm_bwd; the workspace is required. */
 int sconf_norm2_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, void* h2_bf16,
-                    float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t M, int64_t d, float eps1, float eps2,
-                    sconf_stream_t stream);
+                    float* mean1, float* rstd1, float* mean2, float* rstd2, float* mean3, float* rstd3, int twice,
+                    int64_t M, int64_t d, float eps1, float eps2, sconf_stream_t stream);
 int64_t sconf_norm2_bwd_workspace(int64_t M, int64_t d);
-int sconf_norm2_bwd(const void* dh2_bf16, const float* x, const float* w1, const float* b1, const float* w2,
-                    const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, const float* dres,
+int sconf_norm2_bwd(const void* dh2_bf16, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                    const float* mean1, const float* rstd1, const float* mean2, const float* rstd2,
+                    const float* mean3, const float* rstd3, int twice, const float* dres,
                     float* dx, float* dw1, float* db1, float* dw2, float* db2, float* workspace, int64_t workspace_floats,
                     void* dx_bf16, float* dx_colsum, int64_t M, int64_t d, sconf_stream_t stream);
+/* twice != 0: the second norm is applied two times, h2 = LN(LN(y1; w2, b2); w2, b2) - the head's legacy double norm after the last
+ * layer (sconformer_xl.py:246-247, legasee_double_norm); mean3 / rstd3 then hold the statistics of the inner result (else unused). */
 
 int sconf_cast(const void* src, int src_dtype, void* dst, int dst_dtype, int64_t n, sconf_stream_t stream);
 /* dst (C,R) bf16 = transpose(src (R,C) f32): transposed weight shadow so that dgrad GEMMs are NT. */

@@ -294,11 +294,14 @@ int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, 
 // single norms run at the HBM roofline already, so what the fusion buys is bytes: forward 10 instead of 14 B per element (y1 is
 // not re-read), backward 16 instead of 28 (the gradient of y1 never exists in memory, and y1 itself is recomputed from x and the
 // saved row statistics instead of being read).
-template <int MAXIT>
+// TWICE: the second norm is applied two times, h = LN(LN(y1; w2, b2); w2, b2) - the reference's legacy double norm of the head
+// (sconformer_xl.py:246-247 with legasee_double_norm) after the last layer's norm_out; the value in between stays in registers.
+template <int MAXIT, bool TWICE>
 __global__ __launch_bounds__(256) void norm2_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1, const float* __restrict__ b1,
                                                         const float* __restrict__ w2, const float* __restrict__ b2,
                                                         float* __restrict__ y1, bf16* __restrict__ h2, float* __restrict__ mean1,
                                                         float* __restrict__ rstd1, float* __restrict__ mean2, float* __restrict__ rstd2,
+                                                        float* __restrict__ mean3, float* __restrict__ rstd3,
                                                         int M, int d, float eps1, float eps2) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) void norm2_fwd_kernel(const float* __restrict_
         if (c < d) { load4(xr + c, v[it]); s += v[it][0] + v[it][1] + v[it][2] + v[it][3]; }
         else { v[it][0] = v[it][1] = v[it][2] = v[it][3] = 0.f; }
     }
-    // the same two-pass statistics as norm_fwd_kernel, twice
+    // the same two-pass statistics as norm_fwd_kernel
     auto stats = [&](float sum, float eps, float& mean, float& rstd) {
         mean = wave_sum(sum) / d;
         float q = 0.f;
@@ -343,6 +346,21 @@ __global__ __launch_bounds__(256) void norm2_fwd_kernel(const float* __restrict_
     }
     stats(s, eps2, m2, r2);
     if (lane == 0) { mean1[row] = m1; rstd1[row] = r1; mean2[row] = m2; rstd2[row] = r2; }
+    if (TWICE) {
+        s = 0.f;
+#pragma unroll
+        for (int it = 0; it < MAXIT; ++it) {
+            const int c = it * 256 + lane * 4;
+            if (c < d) {
+                float wv[4], bv[4]; load4(w2 + c, wv); load4(b2 + c, bv);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[it][e] = (v[it][e] - m2) * r2 * wv[e] + bv[e];
+                s += v[it][0] + v[it][1] + v[it][2] + v[it][3];
+            }
+        }
+        stats(s, eps2, m2, r2);                           // (m2, r2 now hold the statistics of the third norm's input)
+        if (lane == 0) { mean3[row] = m2; rstd3[row] = r2; }
+    }
     bf16* hr = h2 + (long)row * d;
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
@@ -358,15 +376,19 @@ __global__ __launch_bounds__(256) void norm2_fwd_kernel(const float* __restrict_
 
 // Backward of the pair.  dh2: gradient of h2 (bf16); dres: gradient that reaches y1 directly (f32, nullable).  Per row:
 //   y1 = xhat1 w1 + b1 (recomputed), xhat2 = (y1 - mean2) rstd2,  dy1 = dres + LN'(dh2 at y1),  dx = LN'(dy1 at x).
+// TWICE: one more LN'(. at y2 = xhat2 w2 + b2) in front, with the same w2 (its gradient collects both applications).
 // Parameter gradients of both norms and the column sums of the bf16 twin go to the workgroup's slab [5][d]
 // (dw1 | db1 | dw2 | db2 | colsum), added up in a fixed order by norm2_bwd_reduce_kernel.
-template <int MAXIT, int NB_WAVES>
+template <int MAXIT, int NB_WAVES, bool TWICE>
 __global__ __launch_bounds__(64 * NB_WAVES) void norm2_bwd_kernel(const bf16* __restrict__ dh2, const float* __restrict__ x,
                                                           const float* __restrict__ w1, const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2,
                                                           const float* __restrict__ mean1, const float* __restrict__ rstd1,
                                                           const float* __restrict__ mean2, const float* __restrict__ rstd2,
+                                                          const float* __restrict__ mean3, const float* __restrict__ rstd3,
                                                           const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ ws,
                                                           bf16* __restrict__ dx16, int M, int d) {
+    constexpr bool AHEAD = !TWICE;                          // the three-norm form has no registers left for the row-ahead loads (one launch per step)
     const int lane = threadIdx.x & 63;
     const int wid = blockIdx.x * NB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * NB_WAVES;
     float aw1[MAXIT][4], ab1[MAXIT][4], aw2[MAXIT][4], ab2[MAXIT][4], ac[MAXIT][4], w1v[MAXIT][4], w2v[MAXIT][4];
@@ -377,9 +399,10 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm2_bwd_kernel(const bf16* __
         for (int e = 0; e < 4; ++e) { aw1[it][e] = ab1[it][e] = aw2[it][e] = ab2[it][e] = ac[it][e] = 0.f; w1v[it][e] = w2v[it][e] = 0.f; }
         if (c < d) { load4(w1 + c, w1v[it]); load4(w2 + c, w2v[it]); }
     }
-    struct Row { Raw4<float> x[MAXIT]; Raw4<bf16> g[MAXIT]; Raw4<float> r[MAXIT]; float m1, r1, m2, r2; };
+    struct Row { Raw4<float> x[MAXIT]; Raw4<bf16> g[MAXIT]; Raw4<float> r[MAXIT]; float m1, r1, m2, r2, m3, r3; };
     auto load_row = [&](Row& R, int row) {
         R.m1 = mean1[row]; R.r1 = rstd1[row]; R.m2 = mean2[row]; R.r2 = rstd2[row];
+        if (TWICE) { R.m3 = mean3[row]; R.r3 = rstd3[row]; }
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = it * 256 + lane * 4;
@@ -390,11 +413,12 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm2_bwd_kernel(const bf16* __
         }
     };
     Row nxt;
-    if (wid < M) load_row(nxt, wid);
+    if (AHEAD && wid < M) load_row(nxt, wid);
     for (int row = wid; row < M; row += nw) {
-        Row cur = nxt;
-        if (row + nw < M) load_row(nxt, row + nw);
-        float xh1[MAXIT][4], t[MAXIT][4];                  // t: xhat2, then dy1
+        Row cur;
+        if (AHEAD) { cur = nxt; if (row + nw < M) load_row(nxt, row + nw); }
+        else load_row(cur, row);
+        float xh1[MAXIT][4], xh2[TWICE ? MAXIT : 1][4], t[MAXIT][4];     // t: the innermost xhat, then the gradient flowing outwards
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
@@ -402,31 +426,58 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm2_bwd_kernel(const bf16* __
             if (c < d) {
                 float xv[4], g[4], bv[4];
                 cur.x[it].get(xv); cur.g[it].get(g); load4(b1 + c, bv);
+                float b2v[4] = {0.f, 0.f, 0.f, 0.f};
+                if (TWICE) load4(b2 + c, b2v);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float x1 = (xv[e] - cur.m1) * cur.r1;
                     xh1[it][e] = x1;
-                    const float x2 = (x1 * w1v[it][e] + bv[e] - cur.m2) * cur.r2;
+                    float xin = (x1 * w1v[it][e] + bv[e] - cur.m2) * cur.r2;              // xhat2
+                    if (TWICE) { xh2[it][e] = xin; xin = (xin * w2v[it][e] + b2v[e] - cur.m3) * cur.r3; }   // xhat3
                     const float gw = g[e] * w2v[it][e];
-                    s1 += gw; s2 += gw * x2;
-                    aw2[it][e] += g[e] * x2; ab2[it][e] += g[e];
-                    t[it][e] = x2;
+                    s1 += gw; s2 += gw * xin;
+                    aw2[it][e] += g[e] * xin; ab2[it][e] += g[e];
+                    t[it][e] = xin;
                 }
             }
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
-        const float c1 = cur.r2 * s1 / d, c2 = cur.r2 * s2 / d;
+        const float rin = TWICE ? cur.r3 : cur.r2;
+        float c1 = rin * s1 / d, c2 = rin * s2 / d;
+        if (TWICE) {                                        // through the inner application of (w2, b2): dy2, then the same sums with xhat2
+            float p1 = 0.f, p2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < MAXIT; ++it) {
+                const int c = it * 256 + lane * 4;
+                if (c < d) {
+                    float g[4];
+                    cur.g[it].get(g);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dy2 = cur.r3 * g[e] * w2v[it][e] - c1 - t[it][e] * c2;
+                        t[it][e] = dy2;
+                        const float gw = dy2 * w2v[it][e];
+                        p1 += gw; p2 += gw * xh2[it][e];
+                        aw2[it][e] += dy2 * xh2[it][e]; ab2[it][e] += dy2;
+                    }
+                }
+            }
+            p1 = wave_sum(p1); p2 = wave_sum(p2);
+            c1 = cur.r2 * p1 / d; c2 = cur.r2 * p2 / d;
+        }
         float u1 = 0.f, u2 = 0.f;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
             const int c = it * 256 + lane * 4;
             if (c < d) {
                 float g[4], r[4] = {0.f, 0.f, 0.f, 0.f};
-                cur.g[it].get(g);
+                if (!TWICE) cur.g[it].get(g);
                 if (dres) cur.r[it].get(r);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const float dy1 = r[e] + cur.r2 * g[e] * w2v[it][e] - c1 - t[it][e] * c2;
+                    // gradient entering the (outer) application of (w2, b2) at y1, and xhat2
+                    const float gin = TWICE ? t[it][e] : g[e], x2 = TWICE ? xh2[it][e] : t[it][e];
+                    const float dy1 = r[e] + cur.r2 * gin * w2v[it][e] - c1 - x2 * c2;
                     t[it][e] = dy1;
                     const float gw = dy1 * w1v[it][e];
                     u1 += gw; u2 += gw * xh1[it][e];
@@ -511,15 +562,17 @@ __global__ __launch_bounds__(1024) void norm2_bwd_reduce_kernel(const float* __r
     }
 }
 
-template <int NIT> int launch_norm2_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, bf16* h2,
-                                        float* mean1, float* rstd1, float* mean2, float* rstd2, int M, int d, float eps1, float eps2, hipStream_t st) {
-    hipLaunchKernelGGL((norm2_fwd_kernel<NIT>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, w1, b1, w2, b2, y1, h2, mean1, rstd1, mean2, rstd2, M, d, eps1, eps2);
+template <int NIT> int launch_norm2_fwd(bool twice, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, bf16* h2,
+                                        float* mean1, float* rstd1, float* mean2, float* rstd2, float* mean3, float* rstd3, int M, int d, float eps1, float eps2, hipStream_t st) {
+    if (twice) hipLaunchKernelGGL((norm2_fwd_kernel<NIT, true>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, w1, b1, w2, b2, y1, h2, mean1, rstd1, mean2, rstd2, mean3, rstd3, M, d, eps1, eps2);
+    else hipLaunchKernelGGL((norm2_fwd_kernel<NIT, false>), dim3(cdiv(M, 4)), dim3(256), 0, st, x, w1, b1, w2, b2, y1, h2, mean1, rstd1, mean2, rstd2, mean3, rstd3, M, d, eps1, eps2);
     return 0;
 }
-template <int NIT> int launch_norm2_bwd(const bf16* dh2, const float* x, const float* w1, const float* b1, const float* w2, const float* mean1,
-                                        const float* rstd1, const float* mean2, const float* rstd2, const float* dres, float* dx, float* ws,
+template <int NIT> int launch_norm2_bwd(bool twice, const bf16* dh2, const float* x, const float* w1, const float* b1, const float* w2, const float* b2, const float* mean1,
+                                        const float* rstd1, const float* mean2, const float* rstd2, const float* mean3, const float* rstd3, const float* dres, float* dx, float* ws,
                                         bf16* dx16, int grid, int M, int d, hipStream_t st) {
-    hipLaunchKernelGGL((norm2_bwd_kernel<NIT, NBW>), dim3(grid), dim3(64 * NBW), 0, st, dh2, x, w1, b1, w2, mean1, rstd1, mean2, rstd2, dres, dx, ws, dx16, M, d);
+    if (twice) hipLaunchKernelGGL((norm2_bwd_kernel<NIT, NBW, true>), dim3(grid), dim3(64 * NBW), 0, st, dh2, x, w1, b1, w2, b2, mean1, rstd1, mean2, rstd2, mean3, rstd3, dres, dx, ws, dx16, M, d);
+    else hipLaunchKernelGGL((norm2_bwd_kernel<NIT, NBW, false>), dim3(grid), dim3(64 * NBW), 0, st, dh2, x, w1, b1, w2, b2, mean1, rstd1, mean2, rstd2, mean3, rstd3, dres, dx, ws, dx16, M, d);
     return 0;
 }
 #define NIT_DISPATCH1(FN, ...) do { const int nit_ = (int)((d + 255) / 256); \
@@ -568,33 +621,37 @@ SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void*
     return 0;
 }
 
-// y1 = LayerNorm(x; w1, b1) (f32) and h2 = LayerNorm(y1; w2, b2) (bf16) in one pass over x; the four row statistics are saved for
+// y1 = LayerNorm(x; w1, b1) (f32) and h2 = LayerNorm(y1; w2, b2) (bf16) in one pass over x; the row statistics are saved for
 // sconf_norm2_bwd.  Replaces `norm_out` + the decoder norm that follows it (sconformer_xl.py:371 then 241-247 / decoder.py:23).
+// twice != 0: h2 = LN(LN(y1; w2, b2); w2, b2), the legacy double norm of the head (mean3 / rstd3: statistics of the inner result).
 SCONF_API int sconf_norm2_fwd(const float* x, const float* w1, const float* b1, const float* w2, const float* b2, float* y1, void* h2_bf16,
-                              float* mean1, float* rstd1, float* mean2, float* rstd2, int64_t M, int64_t d, float eps1, float eps2,
-                              hipStream_t stream) {
+                              float* mean1, float* rstd1, float* mean2, float* rstd2, float* mean3, float* rstd3, int twice,
+                              int64_t M, int64_t d, float eps1, float eps2, hipStream_t stream) {
     SCONF_REQUIRE(d % 4 == 0 && d <= 768 && d > 0, "sconf_norm2_fwd: d=%ld must be a multiple of 4 and <= 768", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm2_fwd: too many rows");
+    SCONF_REQUIRE(!twice || (mean3 && rstd3), "sconf_norm2_fwd: twice needs mean3 / rstd3");
     if (M == 0) return 0;
-    NIT_DISPATCH1(launch_norm2_fwd, x, w1, b1, w2, b2, y1, (bf16*)h2_bf16, mean1, rstd1, mean2, rstd2, (int)M, (int)d, eps1, eps2, stream);
+    NIT_DISPATCH1(launch_norm2_fwd, twice != 0, x, w1, b1, w2, b2, y1, (bf16*)h2_bf16, mean1, rstd1, mean2, rstd2, mean3, rstd3, (int)M, (int)d, eps1, eps2, stream);
     SCONF_LAUNCH_OK("sconf_norm2_fwd");
     return 0;
 }
 
-// dx = d(LN1)/dx . (dres + d(LN2)/dy1 . dh2);  dw1/db1/dw2/db2 ACCUMULATED;  dx_bf16 / dx_colsum (both or neither): a bf16 copy of dx and
-// its column sums (overwritten).  workspace: sconf_norm2_bwd_workspace(M, d) floats (required).
+// dx = d(LN1)/dx . (dres + d(LN2)/dy1 . dh2)  [twice: one more d(LN2) in front];  dw1/db1/dw2/db2 ACCUMULATED;  dx_bf16 / dx_colsum (both or
+// neither): a bf16 copy of dx and its column sums (overwritten).  workspace: sconf_norm2_bwd_workspace(M, d) floats (required).
 SCONF_API int64_t sconf_norm2_bwd_workspace(int64_t M, int64_t d) { return (int64_t)min(cdiv(M, NBW), bwd_maxgrid()) * 5 * d; }
-SCONF_API int sconf_norm2_bwd(const void* dh2_bf16, const float* x, const float* w1, const float* b1, const float* w2,
-                              const float* mean1, const float* rstd1, const float* mean2, const float* rstd2, const float* dres,
+SCONF_API int sconf_norm2_bwd(const void* dh2_bf16, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                              const float* mean1, const float* rstd1, const float* mean2, const float* rstd2,
+                              const float* mean3, const float* rstd3, int twice, const float* dres,
                               float* dx, float* dw1, float* db1, float* dw2, float* db2, float* workspace, int64_t workspace_floats,
                               void* dx_bf16, float* dx_colsum, int64_t M, int64_t d, hipStream_t stream) {
     SCONF_REQUIRE(d % 4 == 0 && d <= 768 && d > 0, "sconf_norm2_bwd: d=%ld must be a multiple of 4 and <= 768", (long)d);
     SCONF_REQUIRE(M < (1L << 31), "sconf_norm2_bwd: too many rows");
     SCONF_REQUIRE((dx_bf16 == nullptr) == (dx_colsum == nullptr), "sconf_norm2_bwd: dx_bf16 and dx_colsum go together");
+    SCONF_REQUIRE(!twice || (mean3 && rstd3 && b2), "sconf_norm2_bwd: twice needs mean3 / rstd3 / b2");
     if (M == 0) return 0;
     const int grid = min(cdiv(M, NBW), bwd_maxgrid());
     SCONF_REQUIRE(workspace && workspace_floats >= (int64_t)grid * 5 * d, "sconf_norm2_bwd: workspace of sconf_norm2_bwd_workspace(M, d) floats required");
-    NIT_DISPATCH1(launch_norm2_bwd, (const bf16*)dh2_bf16, x, w1, b1, w2, mean1, rstd1, mean2, rstd2, dres, dx, workspace, (bf16*)dx_bf16, grid, (int)M, (int)d, stream);
+    NIT_DISPATCH1(launch_norm2_bwd, twice != 0, (const bf16*)dh2_bf16, x, w1, b1, w2, b2, mean1, rstd1, mean2, rstd2, mean3, rstd3, dres, dx, workspace, (bf16*)dx_bf16, grid, (int)M, (int)d, stream);
     Norm2Outs outs = {{dw1, db1, dw2, db2, dx_colsum}};
     hipLaunchKernelGGL(norm2_bwd_reduce_kernel, dim3(cdiv(5 * d, 64)), dim3(1024), 0, stream, workspace, outs, grid, (int)d);
     SCONF_LAUNCH_OK("sconf_norm2_bwd");

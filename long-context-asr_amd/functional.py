@@ -277,30 +277,33 @@ def norm(x, weight, bias, mode='layer_norm', eps=1e-5, out_dtype=F32):
 # =================================================================================================
 class Norm2Fn(Function):
     """(y1, h2) = (LN(x; w1, b1) f32, LN(y1; w2, b2) bf16) in one pass; the backward takes both gradients at once, so the gradient
-    of y1 the second norm contributes never exists in memory (16 instead of 28 bytes per element; forward 10 instead of 14)."""
+    of y1 the second norm contributes never exists in memory (16 instead of 28 bytes per element; forward 10 instead of 14).
+    twice: h2 = LN(LN(y1; w2, b2); w2, b2) - norm_out of the LAST layer followed by the head's legacy double norm (36 -> 12 and 22 -> 10)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, eps1: float, eps2: float):
+    def forward(ctx, x, w1, b1, w2, b2, eps1: float, eps2: float, twice: bool):
         x = x.contiguous()
-        y1, h2, st = ops.norm2_fwd(x, w1, b1, w2, b2, eps1, eps2)
-        ctx.save_for_backward(x, w1, b1, w2, *st)
+        y1, h2, st = ops.norm2_fwd(x, w1, b1, w2, b2, eps1, eps2, twice)
+        ctx.save_for_backward(x, w1, b1, w2, b2, *st)
         ctx.P, ctx.eps1 = (w1, b1, w2, b2), eps1
         return y1, h2
 
     @staticmethod
     def backward(ctx, dy1, dh2):
-        x, w1, b1, w2, m1, r1, m2, r2 = ctx.saved_tensors
+        sv = ctx.saved_tensors                            # ONE access: inside a checkpointed region a second unpack raises
+        x, w1, b1, w2, b2 = sv[:5]
+        st = tuple(sv[5:])
         pw1, pb1, pw2, pb2 = ctx.P
         dw1, db1 = _G(pw1), _G(pb1)
         if dh2 is None:                                   # h2 was not used: this is norm_out alone
-            dx, dx16, cs = ops.norm_bwd(dy1.contiguous(), x, w1, m1, r1, 'layer_norm', ctx.eps1, None, F32, dw1.t, db1.t, twin=True)
+            dx, dx16, cs = ops.norm_bwd(dy1.contiguous(), x, w1, st[0], st[1], 'layer_norm', ctx.eps1, None, F32, dw1.t, db1.t, twin=True)
             _park_twin(dx, dx16, cs)
-            return dx, dw1.out(), db1.out(), None, None, None, None
+            return dx, dw1.out(), db1.out(), None, None, None, None, None
         dw2, db2 = _G(pw2), _G(pb2)
-        dx, dx16, cs = ops.norm2_bwd(dh2.contiguous(), x, w1, b1, w2, (m1, r1, m2, r2), None if dy1 is None else dy1.contiguous(),
+        dx, dx16, cs = ops.norm2_bwd(dh2.contiguous(), x, w1, b1, w2, b2, st, None if dy1 is None else dy1.contiguous(),
                                      dw1.t, db1.t, dw2.t, db2.t, twin=True)
         _park_twin(dx, dx16, cs)                          # the layer's last block (ff2) receives dx as its output gradient
-        return dx, dw1.out(), db1.out(), dw2.out(), db2.out(), None, None
+        return dx, dw1.out(), db1.out(), dw2.out(), db2.out(), None, None, None
 
 
 def norm2_enabled(d: int, *modes) -> bool:
@@ -308,8 +311,8 @@ def norm2_enabled(d: int, *modes) -> bool:
     return d % 4 == 0 and d <= 768 and all(m == 'layer_norm' for m in modes) and os.environ.get('SCONF_NORM2', '1') != '0'
 
 
-def norm2(x, w1, b1, w2, b2, eps1=1e-5, eps2=1e-5):
-    return Norm2Fn.apply(x, w1, b1, w2, b2, eps1, eps2)
+def norm2(x, w1, b1, w2, b2, eps1=1e-5, eps2=1e-5, twice=False):
+    return Norm2Fn.apply(x, w1, b1, w2, b2, eps1, eps2, twice)
 
 
 # =================================================================================================
@@ -545,16 +548,21 @@ def selfcond_block(x, nw, nb, wff, bff, wre, bre, has_norm=True, mode='layer_nor
 # =================================================================================================
 class HeadFn(Function):
     @staticmethod
-    def forward(ctx, x, nw, nb, wff, bff, n_norms: int, mode: str, eps: float, return_logits: bool):
-        x = x.contiguous()
+    def forward(ctx, x, hn_pre, nw, nb, wff, bff, n_norms: int, mode: str, eps: float, return_logits: bool):
+        """hn_pre (bf16, optional): the decoder norm(s) of x already applied by the producer of x (Norm2Fn) - x is then unused here
+        and the gradient of hn_pre goes back to the producer."""
         saved_norm = []
-        cur = x
-        for i in range(n_norms):                                                       # legacy double norm: applied twice
-            out_dt = BF16 if i == n_norms - 1 else F32
-            y, mean, rstd = ops.norm_fwd(cur, nw, nb, mode, eps, out_dt)
-            saved_norm += [cur, mean, rstd]
-            cur = y
-        hn = cur if n_norms > 0 else ops.cast(x, BF16)
+        if hn_pre is not None:
+            hn, n_norms = hn_pre.contiguous(), -1
+        else:
+            x = x.contiguous()
+            cur = x
+            for i in range(n_norms):                                                   # legacy double norm: applied twice
+                out_dt = BF16 if i == n_norms - 1 else F32
+                y, mean, rstd = ops.norm_fwd(cur, nw, nb, mode, eps, out_dt)
+                saved_norm += [cur, mean, rstd]
+                cur = y
+            hn = cur if n_norms > 0 else ops.cast(x, BF16)
         wfh = wcast(wff)
         logits = ops.gemm(hn, wfh, 'nt', bias=bff, out_dtype=F32)
         out = logits if return_logits else ops.softmax_fwd(logits, True, F32)
@@ -567,8 +575,9 @@ class HeadFn(Function):
     def backward(ctx, dout):
         n_norms, mode, eps, return_logits = ctx.cfg
         pnw, pnb, pwf, pbf = ctx.P
-        nw, nb, wft, bff, hn, out = ctx.saved_tensors[:6]
-        sn = ctx.saved_tensors[6:]
+        sv = ctx.saved_tensors
+        nw, nb, wft, bff, hn, out = sv[:6]
+        sn = sv[6:]
         dout = dout.contiguous()
         if return_logits:
             dl = ops.cast(dout, BF16)
@@ -579,17 +588,19 @@ class HeadFn(Function):
             dbf = gbf.out()
         dwf = _wgrad(dl, hn, pwf)
         g = ops.gemm(dl, wft, 'nt')                                                    # (M,d) bf16
+        if n_norms < 0:                                                                # pre-normalised input: its producer applies the norms' backward
+            return None, g, None, None, dwf, dbf, None, None, None, None
         dnw, dnb = _G(pnw if n_norms > 0 else None), _G(pnb if n_norms > 0 else None)
         for i in reversed(range(n_norms)):
             xin, mean, rstd = sn[3 * i:3 * i + 3]
             g = ops.norm_bwd(g, xin, nw, mean, rstd, mode, eps, None, F32, dnw.t, dnb.t)
         if n_norms == 0:
             g = ops.cast(g, F32)
-        return g, dnw.out(), dnb.out(), dwf, dbf, None, None, None, None
+        return g, None, dnw.out(), dnb.out(), dwf, dbf, None, None, None, None
 
 
-def decoder_head(x, nw, nb, wff, bff, n_norms=1, mode='layer_norm', eps=1e-5, return_logits=False):
-    return HeadFn.apply(x, nw, nb, wff, bff, n_norms, mode, eps, return_logits)
+def decoder_head(x, nw, nb, wff, bff, n_norms=1, mode='layer_norm', eps=1e-5, return_logits=False, prenormed=None):
+    return HeadFn.apply(x, prenormed, nw, nb, wff, bff, n_norms, mode, eps, return_logits)
 
 
 # =================================================================================================
@@ -604,16 +615,19 @@ class HeadCTCFn(Function):
     and log_softmax backward: 41 GB -> 15 GB around the (B,N,4096) f32 tensors)."""
 
     @staticmethod
-    def forward(ctx, x, nw, nb, wff, bff, n_norms: int, mode: str, eps: float, B: int, targets, input_lengths, target_lengths, blank: int):
-        x = x.contiguous()
+    def forward(ctx, x, hn_pre, nw, nb, wff, bff, n_norms: int, mode: str, eps: float, B: int, targets, input_lengths, target_lengths, blank: int):
         saved_norm = []
-        cur = x
-        for i in range(n_norms):                                                       # legacy double norm: applied twice
-            out_dt = BF16 if i == n_norms - 1 else F32
-            y, mean, rstd = ops.norm_fwd(cur, nw, nb, mode, eps, out_dt)
-            saved_norm += [cur, mean, rstd]
-            cur = y
-        hn = cur if n_norms > 0 else ops.cast(x, BF16)
+        if hn_pre is not None:                                                         # as in HeadFn
+            hn, n_norms = hn_pre.contiguous(), -1
+        else:
+            x = x.contiguous()
+            cur = x
+            for i in range(n_norms):                                                   # legacy double norm: applied twice
+                out_dt = BF16 if i == n_norms - 1 else F32
+                y, mean, rstd = ops.norm_fwd(cur, nw, nb, mode, eps, out_dt)
+                saved_norm += [cur, mean, rstd]
+                cur = y
+            hn = cur if n_norms > 0 else ops.cast(x, BF16)
         logits = ops.gemm(hn, wcast(wff), 'nt', bias=bff, out_dtype=F32)               # (B N, V+1) f32
         lg3 = logits.view(B, -1, logits.shape[-1])
         nll, ws = ops.ctc_fwd_logits(lg3, targets, input_lengths, target_lengths, blank)
@@ -627,9 +641,10 @@ class HeadCTCFn(Function):
     def backward(ctx, dnll):
         n_norms, mode, eps, B, blank, nws = ctx.cfg
         pnw, pnb, pwf, pbf = ctx.P
-        nw, nb, wft, bff, hn, logits, nll, targets, input_lengths, target_lengths = ctx.saved_tensors[:10]
-        ws = tuple(ctx.saved_tensors[10:10 + nws]) if nws else (None, None, None, None)
-        sn = ctx.saved_tensors[10 + nws:]
+        sv = ctx.saved_tensors
+        nw, nb, wft, bff, hn, logits, nll, targets, input_lengths, target_lengths = sv[:10]
+        ws = tuple(sv[10:10 + nws]) if nws else (None, None, None, None)
+        sn = sv[10 + nws:]
         gbf = _G(pbf)
         dl = ops.ctc_bwd_logits(logits.view(B, -1, logits.shape[-1]), ws, nll, targets, input_lengths, target_lengths,
                                 dnll.contiguous().to(F32), blank, colsum_into=gbf.t if pbf is not None else None)
@@ -637,23 +652,25 @@ class HeadCTCFn(Function):
         dbf = gbf.out()
         dwf = _wgrad(dl, hn, pwf)
         g = ops.gemm(dl, wft, 'nt')                                                    # (M,d) bf16
+        if n_norms < 0:
+            return (None, g, None, None, dwf, dbf) + (None,) * 8
         dnw, dnb = _G(pnw if n_norms > 0 else None), _G(pnb if n_norms > 0 else None)
         for i in reversed(range(n_norms)):
             xin, mean, rstd = sn[3 * i:3 * i + 3]
             g = ops.norm_bwd(g, xin, nw, mean, rstd, mode, eps, None, F32, dnw.t, dnb.t)
         if n_norms == 0:
             g = ops.cast(g, F32)
-        return (g, dnw.out(), dnb.out(), dwf, dbf) + (None,) * 8
+        return (g, None, dnw.out(), dnb.out(), dwf, dbf) + (None,) * 8
 
 
-def decoder_head_ctc(x, nw, nb, wff, bff, B, targets, input_lengths, target_lengths, blank, n_norms=1, mode='layer_norm', eps=1e-5):
+def decoder_head_ctc(x, nw, nb, wff, bff, B, targets, input_lengths, target_lengths, blank, n_norms=1, mode='layer_norm', eps=1e-5, prenormed=None):
     """(B,) CTC negative log-likelihoods of the head applied to x (B N, d); integer tensors as for ctc_nll."""
     dev = x.device
     _check_ctc_host_args(targets, input_lengths, target_lengths, x.shape[0] // max(B, 1), wff.shape[0])
     tg = targets.to(device=dev, dtype=torch.int32).contiguous()
     il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
-    return HeadCTCFn.apply(x, nw, nb, wff, bff, n_norms, mode, eps, B, tg, il, tl, blank)
+    return HeadCTCFn.apply(x, prenormed, nw, nb, wff, bff, n_norms, mode, eps, B, tg, il, tl, blank)
 
 
 # =================================================================================================
@@ -721,8 +738,9 @@ class CTCFn(Function):
 
     @staticmethod
     def backward(ctx, dnll):
-        lp, nll, targets, input_lengths, target_lengths = ctx.saved_tensors[:5]
-        ws = tuple(ctx.saved_tensors[5:]) if len(ctx.saved_tensors) > 5 else (None, None, None)
+        sv = ctx.saved_tensors
+        lp, nll, targets, input_lengths, target_lengths = sv[:5]
+        ws = tuple(sv[5:]) if len(sv) > 5 else (None, None, None)
         g = ops.ctc_bwd(lp, ws, nll, targets, input_lengths, target_lengths, dnll.contiguous().to(F32), ctx.blank)
         return g, None, None, None, None
 

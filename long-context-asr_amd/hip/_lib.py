@@ -20,8 +20,8 @@ PROTOTYPES = {
     'sconf_splitk_reduce': [vp, vp, i64, i64, i32, vp],
     'sconf_norm_fwd': [i32, vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, f32, vp],
     'sconf_norm_bwd': [i32, vp, i32, vp, i32, vp, vp, vp, vp, vp, i32, vp, vp, vp, i64, vp, vp, i64, i64, f32, vp],
-    'sconf_norm2_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, f32, f32, vp],
-    'sconf_norm2_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i64, vp],
+    'sconf_norm2_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, i64, f32, f32, vp],
+    'sconf_norm2_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, i64, i64, vp],
     'sconf_cast': [vp, i32, vp, i32, i64, vp],
     'sconf_cast_transpose': [vp, vp, i64, i64, vp],
     'sconf_cast_shadows': [vp, i64, i64, vp],

@@ -173,35 +173,38 @@ def norm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, mean: torc
     return (dx, dx16, cs) if twin else dx
 
 
-def norm2_fwd(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, eps1: float, eps2: float):
-    """y1 = LayerNorm(x; w1, b1) (f32) and h2 = LayerNorm(y1; w2, b2) (bf16) in one pass (d <= 768).
-    Returns (y1, h2, stats) with stats = (mean1, rstd1, mean2, rstd2), f32 per row."""
+def norm2_fwd(x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, eps1: float, eps2: float,
+              twice: bool = False):
+    """y1 = LayerNorm(x; w1, b1) (f32) and h2 = LayerNorm(y1; w2, b2) (bf16) in one pass (d <= 768); twice: the second norm is
+    applied two times (the head's legacy double norm).  Returns (y1, h2, stats): stats = (mean1, rstd1, mean2, rstd2[, mean3, rstd3])."""
     _chk(x, 'x', torch.float32)
     for n, t in (('w1', w1), ('b1', b1), ('w2', w2), ('b2', b2)): _chk(t, n, torch.float32)
     d = x.shape[-1]; M = x.numel() // d
     y1 = torch.empty_like(x)
     h2 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
-    st = torch.empty(4, M, dtype=torch.float32, device=x.device)
+    ns = 6 if twice else 4
+    st = torch.empty(ns, M, dtype=torch.float32, device=x.device)
     _lib.call('sconf_norm2_fwd', _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(y1), _p(h2), _p(st[0]), _p(st[1]), _p(st[2]), _p(st[3]),
-              M, d, float(eps1), float(eps2), _stream())
-    return y1, h2, (st[0], st[1], st[2], st[3])
+              _p(st[4]) if twice else None, _p(st[5]) if twice else None, int(twice), M, d, float(eps1), float(eps2), _stream())
+    return y1, h2, tuple(st[i] for i in range(ns))
 
 
-def norm2_bwd(dh2: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, stats, dres: Optional[torch.Tensor],
-              dw1: torch.Tensor, db1: torch.Tensor, dw2: torch.Tensor, db2: torch.Tensor, twin: bool = False):
-    """Backward of norm2_fwd: dx = LN1'(dres + LN2'(dh2)); the four parameter gradients are accumulated in place (f32).
-    twin=True also returns (dx16, colsum) as norm_bwd does."""
+def norm2_bwd(dh2: torch.Tensor, x: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, stats,
+              dres: Optional[torch.Tensor], dw1: torch.Tensor, db1: torch.Tensor, dw2: torch.Tensor, db2: torch.Tensor, twin: bool = False):
+    """Backward of norm2_fwd (six statistics: the twice form): dx = LN1'(dres + LN2'(dh2)); the four parameter gradients are
+    accumulated in place (f32).  twin=True also returns (dx16, colsum) as norm_bwd does."""
     _chk(dh2, 'dh2', torch.bfloat16); _chk(x, 'x', torch.float32)
     for n, t in (('dw1', dw1), ('db1', db1), ('dw2', dw2), ('db2', db2)): _chk(t, n, torch.float32)
     if dres is not None: _chk(dres, 'dres', torch.float32)
     d = x.shape[-1]; M = x.numel() // d
-    m1, r1, m2, r2 = stats
+    twice = len(stats) == 6
     dx = torch.empty_like(x)
     nws = int(_lib.load().sconf_norm2_bwd_workspace(M, d))
     ws = torch.empty(nws, dtype=torch.float32, device=x.device)
     dx16 = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if twin else None
     cs = torch.empty(d, dtype=torch.float32, device=x.device) if twin else None
-    _lib.call('sconf_norm2_bwd', _p(dh2), _p(x), _p(w1), _p(b1), _p(w2), _p(m1), _p(r1), _p(m2), _p(r2), _p(dres), _p(dx),
+    _lib.call('sconf_norm2_bwd', _p(dh2), _p(x), _p(w1), _p(b1), _p(w2), _p(b2), _p(stats[0]), _p(stats[1]), _p(stats[2]), _p(stats[3]),
+              _p(stats[4]) if twice else None, _p(stats[5]) if twice else None, int(twice), _p(dres), _p(dx),
               _p(dw1), _p(db1), _p(dw2), _p(db2), _p(ws), nws, _p(dx16), _p(cs), M, d, _stream())
     return (dx, dx16, cs) if twin else dx
 

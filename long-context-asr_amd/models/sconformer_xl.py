@@ -110,10 +110,14 @@ class SCConformerXL(BaseModel):
             rotary = (cos[:N], sin[:N]) if n_rot > N else (cos, sin)
         lengths_dev = None if max(len_host) == min(len_host) else length.to(device=dev, dtype=torch.int32).contiguous()
 
+        extra = 1 if self.legasee_double_norm else 0
+        h = None
         for lth, layer in enumerate(self.layers):
-            sc = lth != len(self.layers) - 1 and self.self_conditioning
-            # the decoder norm of the self-conditioning step is applied by the layer together with its norm_out (one pass)
-            post = dec.post_norm_spec(x.shape[-1], layer.norm_out.mode) if sc else None
+            last = lth == len(self.layers) - 1
+            sc = not last and self.self_conditioning
+            # the decoder norm of the self-conditioning step - after the last layer: the head's norm(s) - is applied by the layer
+            # together with its norm_out (one pass)
+            post = dec.post_norm_spec(x.shape[-1], layer.norm_out.mode, extra if last else 0) if (sc or last) else None
             h = None
             if self.checkpoint_every_n_layers > 0 and lth % self.checkpoint_every_n_layers == 0:
                 if post is None:
@@ -128,11 +132,11 @@ class SCConformerXL(BaseModel):
                 h = None if post is None else post.get('h')
             if sc:
                 x = dec.self_condition(x, prenormed=h)
-        extra = 1 if self.legasee_double_norm else 0
         if ctc_targets is not None:
-            out = {'final_posteriors': None, 'length': length, 'ctc_nll': dec.ctc_nll(x, ctc_targets[0], length, ctc_targets[1], extra_norms=extra)}
+            out = {'final_posteriors': None, 'length': length,
+                   'ctc_nll': dec.ctc_nll(x, ctc_targets[0], length, ctc_targets[1], extra_norms=extra, prenormed=h)}
         else:
-            out = {'final_posteriors': dec(x, logits=return_logits, extra_norms=extra), 'length': length}
+            out = {'final_posteriors': dec(x, logits=return_logits, extra_norms=extra, prenormed=h), 'length': length}
         if self.training and self.rotary_pos_emb is not None:
             self.rotary_pos_emb.reset_if_needed()
         return out
@@ -173,7 +177,8 @@ class ConformerLayer(nn.Module):
         if post_norm is not None:
             nw, nb = self.norm_out.norm_params()
             shape = x.shape
-            y, h = Fn.norm2(x.reshape(-1, shape[-1]), nw, nb, post_norm['w'], post_norm['b'], self.norm_out.eps, post_norm['eps'])
+            y, h = Fn.norm2(x.reshape(-1, shape[-1]), nw, nb, post_norm['w'], post_norm['b'], self.norm_out.eps, post_norm['eps'],
+                            post_norm.get('twice', False))
             post_norm['h'] = h.view(shape)
             return y.view(shape)
         return self.norm_out(x)

@@ -105,17 +105,26 @@ def norm_bwd(dy, x, weight, mean, rstd, mode, eps, dres, dx_dtype, dweight, dbia
     return dx.to(dx_dtype)
 
 
-def norm2_fwd(x, w1, b1, w2, b2, eps1, eps2):
+def norm2_fwd(x, w1, b1, w2, b2, eps1, eps2, twice=False):
     y1, m1, r1 = norm_fwd(x, w1, b1, 'layer_norm', eps1, f32)
-    h2, m2, r2 = norm_fwd(y1, w2, b2, 'layer_norm', eps2, torch.bfloat16)
-    return y1, h2, (m1, r1, m2, r2)
+    if not twice:
+        h2, m2, r2 = norm_fwd(y1, w2, b2, 'layer_norm', eps2, torch.bfloat16)
+        return y1, h2, (m1, r1, m2, r2)
+    y2, m2, r2 = norm_fwd(y1, w2, b2, 'layer_norm', eps2, f32)
+    h3, m3, r3 = norm_fwd(y2, w2, b2, 'layer_norm', eps2, torch.bfloat16)
+    return y1, h3, (m1, r1, m2, r2, m3, r3)
 
 
-def norm2_bwd(dh2, x, w1, b1, w2, stats, dres, dw1, db1, dw2, db2, twin=False):
-    m1, r1, m2, r2 = stats
+def norm2_bwd(dh2, x, w1, b1, w2, b2, stats, dres, dw1, db1, dw2, db2, twin=False):
+    m1, r1, m2, r2 = stats[:4]
     y1 = ((x.to(f32) - m1.view(-1, 1)) * r1.view(-1, 1)).view(x.shape) * w1 + b1
-    dy1 = norm_bwd(dh2, y1, w2, m2, r2, 'layer_norm', 0.0, dres, f32, dw2, db2)
-    return norm_bwd(dy1, x, w1, m1, r1, 'layer_norm', 0.0, None, f32, dw1, db1, twin=twin)
+    g = dh2
+    if len(stats) == 6:
+        m3, r3 = stats[4:]
+        y2 = ((y1 - m2.view(-1, 1)) * r2.view(-1, 1)).view(x.shape) * w2 + b2
+        g = norm_bwd(dh2, y2, w2, m3, r3, 'layer_norm', 1e-5, None, f32, dw2, db2)
+    dy1 = norm_bwd(g, y1, w2, m2, r2, 'layer_norm', 1e-5, dres, f32, dw2, db2)
+    return norm_bwd(dy1, x, w1, m1, r1, 'layer_norm', 1e-5, None, f32, dw1, db1, twin=twin)
 
 
 def cast(x, dtype): return x.to(dtype)

@@ -198,40 +198,50 @@ def test_norm_fwd_bwd(ops, mode, d):
         close(dw2, dwr, name='norm_bwd dw (twin call)', tol=5e-3)
 
 
+@pytest.mark.parametrize('twice', [False, True])
 @pytest.mark.parametrize('d', [64, 256, 768])
-def test_norm2_fwd_bwd(ops, d):
-    """Two LayerNorms in one pass (norm_out + decoder norm): against the two single-norm kernels (same arithmetic; hipcc contracts the
-    normalisation differently in the two kernels, so the last f32 bit may differ) and against the torch reference."""
+def test_norm2_fwd_bwd(ops, d, twice):
+    """Two (twice: three, the last two with the same parameters - the head's legacy double norm) LayerNorms in one pass: against
+    the single-norm kernels (same arithmetic; hipcc contracts the normalisation differently in the two kernels, so the last f32
+    bit may differ) and against the torch reference."""
     M = 1029                                              # several rows per wave of the persistent backward, ragged tail
     x = rnd(M, d, dtype=F32, scale=2.0) + 0.5
     w1 = rnd(d, dtype=F32, seed=1) * 0.1 + 1.0; b1 = rnd(d, dtype=F32, seed=2) * 0.1
     w2 = rnd(d, dtype=F32, seed=5) * 0.1 + 1.0; b2 = rnd(d, dtype=F32, seed=6) * 0.1
-    y1, h2, st = ops.norm2_fwd(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), 1e-5, 1e-5)
+    y1, h2, st = ops.norm2_fwd(dev(x), dev(w1), dev(b1), dev(w2), dev(b2), 1e-5, 1e-5, twice)
+    assert len(st) == (6 if twice else 4)
     ya, ma, ra = ops.norm_fwd(dev(x), dev(w1), dev(b1), 'layer_norm', 1e-5, F32)
-    hb, mb, rb = ops.norm_fwd(ya, dev(w2), dev(b2), 'layer_norm', 1e-5, BF)
+    if twice:
+        yb, mb, rb = ops.norm_fwd(ya, dev(w2), dev(b2), 'layer_norm', 1e-5, F32)
+        hb, mc, rc = ops.norm_fwd(yb, dev(w2), dev(b2), 'layer_norm', 1e-5, BF)
+    else:
+        hb, mb, rb = ops.norm_fwd(ya, dev(w2), dev(b2), 'layer_norm', 1e-5, BF)
     close(y1, ya.cpu(), name='norm2 y1 vs norm_fwd', tol=1e-6); close(h2, hb.cpu(), name='norm2 h2 vs norm_fwd')
     close(st[0], ma.cpu(), name='norm2 mean1', tol=1e-6, floor=1e-3); close(st[1], ra.cpu(), name='norm2 rstd1', tol=1e-6)
     close(st[2], mb.cpu(), name='norm2 mean2', tol=1e-5, floor=1e-3); close(st[3], rb.cpu(), name='norm2 rstd2', tol=1e-5)
-    y1r, h2r, _ = R.norm2_fwd(x, w1, b1, w2, b2, 1e-5, 1e-5)
+    if twice: close(st[4], mc.cpu(), name='norm2 mean3', tol=1e-5, floor=1e-3); close(st[5], rc.cpu(), name='norm2 rstd3', tol=1e-5)
+    y1r, h2r, _ = R.norm2_fwd(x, w1, b1, w2, b2, 1e-5, 1e-5, twice)
     close(y1, y1r, name='norm2 y1'); close(h2, h2r, name='norm2 h2')
     dh2 = rnd(M, d, dtype=BF, seed=3)
     for dres in (rnd(M, d, dtype=F32, seed=4), None):
         g = [torch.zeros(d).cuda() for _ in range(4)]
-        dx, dx16, cs = ops.norm2_bwd(dev(dh2), dev(x), dev(w1), dev(b1), dev(w2), st, dev(dres), *g, twin=True)
-        # the unfused pair on the device (materialises the gradient of y1)
+        dx, dx16, cs = ops.norm2_bwd(dev(dh2), dev(x), dev(w1), dev(b1), dev(w2), dev(b2), st, dev(dres), *g, twin=True)
+        # the unfused chain on the device (materialises the gradients in between)
         u = [torch.zeros(d).cuda() for _ in range(4)]
-        dy1 = ops.norm_bwd(dev(dh2), ya, dev(w2), mb, rb, 'layer_norm', 1e-5, dev(dres), F32, u[2], u[3])
+        gin = dev(dh2)
+        if twice: gin = ops.norm_bwd(gin, yb, dev(w2), mc, rc, 'layer_norm', 1e-5, None, F32, u[2], u[3])
+        dy1 = ops.norm_bwd(gin, ya, dev(w2), mb, rb, 'layer_norm', 1e-5, dev(dres), F32, u[2], u[3])
         dxu = ops.norm_bwd(dy1, dev(x), dev(w1), ma, ra, 'layer_norm', 1e-5, None, F32, u[0], u[1])
-        close(dx, dxu.cpu(), name='norm2_bwd dx vs two kernels', tol=2e-4)
-        for a, b_, n in zip(g, u, ('dw1', 'db1', 'dw2', 'db2')): close(a, b_.cpu(), name=f'norm2_bwd {n} vs two kernels', tol=1e-3)
+        close(dx, dxu.cpu(), name='norm2_bwd dx vs single kernels', tol=2e-4)
+        for a, b_, n in zip(g, u, ('dw1', 'db1', 'dw2', 'db2')): close(a, b_.cpu(), name=f'norm2_bwd {n} vs single kernels', tol=1e-3)
         # torch reference
         r = [torch.zeros(d) for _ in range(4)]
-        dxr = R.norm2_bwd(dh2, x, w1, b1, w2, tuple(t.cpu() for t in st), dres, *r)
+        dxr = R.norm2_bwd(dh2, x, w1, b1, w2, b2, tuple(t.cpu() for t in st), dres, *r)
         close(dx, dxr, name='norm2_bwd dx', tol=5e-3)
         for a, b_, n in zip(g, r, ('dw1', 'db1', 'dw2', 'db2')): close(a, b_, name=f'norm2_bwd {n}', tol=5e-3)
         assert torch.equal(dx16, dx.to(BF))
         close(cs, dx.to(BF).float().sum(0).cpu(), name='norm2_bwd twin colsum', tol=2e-3)
-        dx_only = ops.norm2_bwd(dev(dh2), dev(x), dev(w1), dev(b1), dev(w2), st, dev(dres), *[torch.zeros(d).cuda() for _ in range(4)])
+        dx_only = ops.norm2_bwd(dev(dh2), dev(x), dev(w1), dev(b1), dev(w2), dev(b2), st, dev(dres), *[torch.zeros(d).cuda() for _ in range(4)])
         assert torch.equal(dx_only, dx)
 
 
