@@ -40,6 +40,13 @@ int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C, int64_t M
                     const void* aux, int64_t ldaux, void* pre, int64_t ldpre, float alpha, int act, int out_f32,
                     int split_k, sconf_stream_t stream);
 
+/* qkv projection with the rotary rotation in the GEMM epilogue (attention.py:485,498-507 + rotary_emb.py:61-73 without a pass over
+ * the activation): C (M, 3, H, D) bf16 = [q | k | v] = x W^T (+ bias), W (3 H D, K) bf16 in the REGROUPED row order (sconf_cast_shadows
+ * with R < 0; bias regrouped the same way), q and k rotated by the NeoX rotary of position (row % seq_len); cos / sin (seq_len, D/2) f32.
+ * head_dim 128 with M, 3 H D multiples of 256 runs the fused epilogue; other shapes run sconf_gemm_bf16 + sconf_rotary_inplace. */
+int sconf_gemm_qkv_rotary(const void* A, const void* W, void* C, int64_t M, int64_t K, int64_t H, int64_t D,
+                          int64_t lda, int64_t ldb, const float* bias, const float* cos_tab, const float* sin_tab,
+                          int64_t seq_len, sconf_stream_t stream);
 int sconf_gemm_num_splits(int64_t K, int split_k);
 /* Which kernel sconf_gemm_bf16 runs for a problem (bookkeeping for benchmarks): 0 = 128x128-tile kernel, 1 / 2 = 256-row NT
  * kernel with 256 / 192-wide tiles, 3 = 256x256 TN kernel; -1 = invalid arguments. */

@@ -297,6 +297,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 
 // C ABI -----------------------------------------------------------------------------------------
 // layout: 0 = NT (A[M][K], B[N][K]); 1 = NN (A[M][K], B[K][N]); 2 = TN (A[K][M], B[K][N]).
+namespace { struct RotSpec { const float* cos = nullptr; const float* sin = nullptr; int n = 0, cols = 0; }; thread_local RotSpec g_rot; }
+
 // Replaces: F.linear / fused_dense_cuda.linear_act_forward (fused_dense.py:277-279,329-332),
 // bias_act_linear_dgrad_bgrad (:354-356), linear_bias_wgrad (:113-115,338-340,375-378).
 SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
@@ -335,6 +337,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.stamps = g_probe_stamps;
 #endif
     { const char* e = getenv("SCONF_GEMM_GM"); p.gm = e ? atoi(e) : 0; }                  // tuning: L2 patch height of the 256-row kernels
+    p.rot_cos = g_rot.cos; p.rot_sin = g_rot.sin; p.rot_n = g_rot.n; p.rot_cols = g_rot.cols;   // set only inside sconf_gemm_qkv_rotary
     const int nkt = cdiv(K, BK);
     p.k_per_split = cdiv(nkt, split_k) * BK;
     const int splits = cdiv(K, p.k_per_split);
@@ -342,6 +345,10 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.split_stride = splits > 1 ? M * ldc : 0;
     if (splits > 1) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
 
+    if (p.rot_cos) {                                   // only the 256-wide NT kernel has the rotary epilogue: the caller falls back otherwise
+        if (getenv("SCONF_GEMM_NO_256") || !sconf_gemm256_eligible(p, layout)) return 2;
+        return sconf_gemm256_launch(p, layout, stream);
+    }
     // A/B switch (read per call so that one process can compare both kernels): keep everything on the 128x128 kernel
     if (!getenv("SCONF_GEMM_NO_256") && sconf_gemm256_eligible(p, layout)) return sconf_gemm256_launch(p, layout, stream);
 
@@ -376,6 +383,29 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     }
     SCONF_LAUNCH_OK("sconf_gemm_bf16");
     return 0;
+}
+
+SCONF_API int sconf_rotary_inplace(void* qkv, const float* cos_tab, const float* sin_tab, int64_t B, int64_t N, int64_t H, int64_t D, hipStream_t stream);
+
+// qkv projection with the rotary rotation in the GEMM epilogue: C (M, 3, H, D) bf16 = [q | k | v] = x W^T (+ bias) with W in the
+// REGROUPED row order (sconf_cast_shadows, R < 0) and q, k rotated by the NeoX rotary of position (row % seq_len) - attention.py:485,
+// 498-507 + rotary_emb.py:61-73 with no pass over the activation.  cos / sin: (seq_len, D/2) f32.  head_dim 128 through the 256x256
+// kernel; any other shape runs the plain GEMM followed by sconf_rotary_inplace (same result up to one bf16 rounding).
+SCONF_API int sconf_gemm_qkv_rotary(const void* A, const void* W, void* C, int64_t M, int64_t K, int64_t H, int64_t D,
+                                    int64_t lda, int64_t ldb, const float* bias, const float* cos_tab, const float* sin_tab,
+                                    int64_t seq_len, hipStream_t stream) {
+    SCONF_REQUIRE(cos_tab && sin_tab && seq_len > 0 && M % seq_len == 0, "sconf_gemm_qkv_rotary: tables / seq_len (M=%ld seq_len=%ld)", (long)M, (long)seq_len);
+    const int64_t N = 3 * H * D;
+    int rc = 2;
+    if (D == 128 && !getenv("SCONF_QKV_ROT_EPILOGUE_OFF")) {
+        g_rot.cos = cos_tab; g_rot.sin = sin_tab; g_rot.n = (int)seq_len; g_rot.cols = (int)(2 * H * D);
+        rc = sconf_gemm_bf16(0, A, W, C, M, N, K, lda, ldb, N, bias, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, SCONF_ACT_NONE, 0, 1, stream);
+        g_rot = RotSpec();
+    }
+    if (rc != 2) return rc;
+    rc = sconf_gemm_bf16(0, A, W, C, M, N, K, lda, ldb, N, bias, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, SCONF_ACT_NONE, 0, 1, stream);
+    if (rc) return rc;
+    return sconf_rotary_inplace(C, cos_tab, sin_tab, M / seq_len, seq_len, H, D, stream);
 }
 
 // Which kernel sconf_gemm_bf16 runs for a problem (diagnostics / benchmark bookkeeping; same decision code as the launch):

@@ -60,7 +60,9 @@ __device__ __forceinline__ int swz_b1n(int row) { return ((row >> 1) & 1) | (((r
 // per-lane source byte offsets (relative to the half-tile's wave-uniform base) of the DMA pieces of each half
 template <bool KS, bool BOP, int JH> struct DmaOffs {
     unsigned off[2][2];
-    __device__ __forceinline__ void set(long ld, int tid) {
+    // rot (B operand of the 256-wide tile only): the wave's lo / hi column runs are d and d + 64 of ONE head (tile = 2 heads of 128),
+    // so that a lane holds both partners of the rotary rotation: wave wc takes head wc >> 1, d in [32 (wc & 1), +32) | that + 64.
+    __device__ __forceinline__ void set(long ld, int tid, bool rot = false) {
         constexpr int WC = 32 + 16 * JH;
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -71,8 +73,8 @@ template <bool KS, bool BOP, int JH> struct DmaOffs {
                     const int row = c >> 3, pos = c & 7;
                     int kc, mrow;
                     if (!BOP)              { kc = pos ^ swz_a(row); mrow = 128 * h + row; }
-                    else if (h == 0)       { kc = pos ^ swz_b(row); mrow = WC * (row >> 5) + (row & 31); }
-                    else if (JH == 2)      { kc = pos ^ swz_b(row); mrow = WC * (row >> 5) + 32 + (row & 31); }
+                    else if (h == 0)       { kc = pos ^ swz_b(row); mrow = rot ? 128 * (row >> 6) + 32 * ((row >> 5) & 1) + (row & 31) : WC * (row >> 5) + (row & 31); }
+                    else if (JH == 2)      { kc = pos ^ swz_b(row); mrow = rot ? 128 * (row >> 6) + 32 * ((row >> 5) & 1) + 64 + (row & 31) : WC * (row >> 5) + 32 + (row & 31); }
                     else                   { kc = pos ^ swz_b1n(row & 63); mrow = WC * ((row & 63) >> 4) + 32 + (row & 15); }
                     off[h][i] = (unsigned)(((long)mrow * ld + kc * 8) * 2);
                 } else {
@@ -185,11 +187,50 @@ struct Cursor {
 template <int W> struct RawBf;
 template <> struct RawBf<8> { typedef bf16x8 type; };
 template <> struct RawBf<4> { typedef bf16x4 type; };
-template <int ACT, bool RES, bool KS, int JH, int FL = -1>
+template <int ACT, bool RES, bool KS, int JH, int FL = -1, bool ROT = false>
 __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[2][4][2 + JH], const Item& it, int wr, int wc, int lane) {
     constexpr int WC = 32 + 16 * JH, WH = 4 * JH;
     constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX;
     const int g = lane >> 4, mbase = it.m0 + 64 * wr + (lane & 15);
+    if constexpr (ROT) {
+        // qkv projection with the rotary rotation: with the rot row permutation (DmaOffs::set) the lane's lo run is (head, d0 .. d0 + 7)
+        // and its hi run (head, d0 + 64 ..): out[d] = x[d] cos - x[d + 64] sin, out[d + 64] = x[d + 64] cos + x[d] sin
+        // (apply_rotary_pos_emb, rotary_emb.py:61-73) on the f32 accumulators - one bf16 rounding instead of two.  Tiles past
+        // rot_cols (the v block) are stored as they are.  cos / sin of the next row block are requested before this one is stored.
+        static_assert(JH == 2 && !RES && !AUX && ACT == SCONF_ACT_NONE && FL >= 0 && !(FL & 2), "rotary epilogue: 256-wide tile, plain bf16 output");
+        const int d0 = 32 * (wc & 1) + 8 * g;
+        const int nlo = it.n0 + 128 * (wc >> 1) + d0, nhi = nlo + 64;
+        float blo[8], bhi[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { blo[e] = 0.f; bhi[e] = 0.f; }
+        if (FL & 1) { loadv<8>(p.bias + nlo, blo); loadv<8>(p.bias + nhi, bhi); }
+        const bool rot = it.n0 < p.rot_cols;                                       // uniform over the workgroup
+        const long crow0 = (long)mbase * p.ldc;
+        float cs[2][8], sn[2][8];
+        auto fetch = [&](int rb, int slot) {
+            const int pos = (mbase + 128 * (rb >> 2) + 16 * (rb & 3)) % p.rot_n;
+            loadv<8>(p.rot_cos + (long)pos * 64 + d0, cs[slot]); loadv<8>(p.rot_sin + (long)pos * 64 + d0, sn[slot]);
+        };
+        if (rot) fetch(0, 0);
+#pragma unroll
+        for (int rb = 0; rb < 8; ++rb) {
+            if (rot && rb + 1 < 8) fetch(rb + 1, (rb + 1) & 1);
+            const int h = rb >> 2, i = rb & 3, sl = rb & 1;
+            float lo[8], hi[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { lo[e] = acc[h][i][e >> 2][e & 3] + blo[e]; hi[e] = acc[h][i][2 + (e >> 2)][e & 3] + bhi[e]; }
+            if (rot) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float a = lo[e], b = hi[e];
+                    lo[e] = a * cs[sl][e] - b * sn[sl][e]; hi[e] = b * cs[sl][e] + a * sn[sl][e];
+                }
+            }
+            const long crow = crow0 + (long)(128 * h + 16 * i) * p.ldc;
+            storev<8>(reinterpret_cast<bf16*>(p.C) + crow + nlo, lo); storev<8>(reinterpret_cast<bf16*>(p.C) + crow + nhi, hi);
+        }
+        return;
+    }
     if constexpr (!KS) {
         const int nlo = it.n0 + WC * wc + 8 * g, nhi = it.n0 + WC * wc + 32 + WH * g;
         float blo[8], bhi[WH];
@@ -308,7 +349,9 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
 // One specialised, contiguous epilogue per (activation, residual, bias, output type) combination the model's NT GEMMs use;
 // `kind` is computed once per launch (wave-uniform), everything else takes the runtime-flag path.
 //   0 bf16 plain   1 bf16 + bias   2 f32 + residual   3 f32 + residual + bias   4 gelu' save (no bias)   5 * aux   6 generic
+//   7 bf16 + rotary   8 bf16 + bias + rotary   (256-wide tile only)
 __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
+    if (p.rot_cos) return p.bias ? 8 : 7;                        // (the launcher has checked everything else)
     const bool b = p.bias != nullptr, unit = p.alpha == 1.f;   // kinds 0, 1, 4 skip the alpha * v + residual step (the FF dgrad, kind 5, carries the branch scale in alpha)
     if (p.act == SCONF_ACT_GELU_DSAVE) return (!b && !p.out_f32 && !p.resid && unit) ? 4 : 6;
     if (p.act == SCONF_ACT_MULAUX) return (!b && !p.out_f32 && !p.resid && !p.pre) ? 5 : 6;
@@ -325,6 +368,8 @@ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
         case 3: epilogue256<SCONF_ACT_NONE, true, false, JH_, 3>(p, acc, cit, wr, wc, lane); break;                   \
         case 4: epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_, 4>(p, acc, cit, wr, wc, lane); break;            \
         case 5: epilogue256<SCONF_ACT_MULAUX, false, false, JH_, 0>(p, acc, cit, wr, wc, lane); break;                \
+        case 7: if constexpr (JH_ == 2) epilogue256<SCONF_ACT_NONE, false, false, JH_, 0, true>(p, acc, cit, wr, wc, lane); break;  \
+        case 8: if constexpr (JH_ == 2) epilogue256<SCONF_ACT_NONE, false, false, JH_, 1, true>(p, acc, cit, wr, wc, lane); break;  \
         default:                                                                                                      \
             if (p.act == SCONF_ACT_GELU_DSAVE)  epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_>(p, acc, cit, wr, wc, lane); \
             else if (p.act == SCONF_ACT_MULAUX) epilogue256<SCONF_ACT_MULAUX, false, false, JH_>(p, acc, cit, wr, wc, lane);     \
@@ -361,7 +406,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
     const int ekind = __builtin_amdgcn_readfirstlane(epilogue_kind(p));
     DmaOffs<KS, false, JH> oa; DmaOffs<KS, true, JH> ob;
-    oa.set(p.lda, tid); ob.set(p.ldb, tid);
+    oa.set(p.lda, tid); ob.set(p.ldb, tid, !KS && JH == 2 && p.rot_cos != nullptr);
     auto issue_a = [&](const Cursor& c, int h) {
         if (!c.valid) return;
         const long k0 = c.it.kbeg + c.kt * TK;
@@ -688,6 +733,7 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
 
 // Tile width for the NT layout: fewest "rounds x width" over the CUs (ties -> the wider tile); 0 = not eligible.
 static int pick_width(const GemmParams& p, int layout, int cus) {
+    if (p.rot_cos) return (layout == 0 && p.N % 256 == 0) ? 256 : 0;          // the rotary epilogue exists for the 256-wide tile
     if (p.M % TM || p.K % TK || p.k_per_split % TK) return 0;
     if (const char* e = getenv("SCONF_GEMM_256_WIDTH")) {                 // benchmarking override
         const int w = atoi(e);

@@ -20,6 +20,9 @@ struct GemmParams {
     int k_per_split;                                // multiple of BK
     int splits;
     int gm;                                         // row panels per L2 patch of the 256-row kernels (0 = default)
+    // NeoX rotary fused into the epilogue of the qkv projection (sconf_gemm_qkv_rotary; 256x256 NT kernel, head_dim 128): output
+    // columns < rot_cols are (head, d) with d < 128; row r is position r % rot_n; tables (rot_n, 64) f32.  null = no rotation.
+    const float* rot_cos; const float* rot_sin; int rot_n, rot_cols;
 #ifdef SCONF_GEMM_PROBE
     int debug;                                      // probe builds only (make PROBE=1; SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
     long long* stamps;                              // probe: per workgroup [64 items][4] {realtime at epilogue start, cycles at start, at end, after the next item's first wait}

@@ -384,9 +384,10 @@ class AttnBlockFn(Function):
             ops.mask_rows_(h, lengths, B, N)                                          # attention.py:511
         wqh, woh = wcast(wqkv, regroup=True), wcast(wout)
         bq = None if bqkv is None else _regrouped(bqkv.detach().view(-1, 1)).view(-1).contiguous()
-        qkv = ops.gemm(h, wqh, 'nt', bias=bq)                                         # (M, 3*H*D) = (B, N, 3, H, D)
-        if cos is not None:
-            ops.rotary_inplace_(qkv, cos, sin, B, N, H, D)
+        if cos is not None:                                                           # rotation in the GEMM epilogue (head_dim 128), else in place
+            qkv = ops.gemm_qkv_rotary(h, wqh, bq, cos, sin, N, H, D)                  # (M, 3*H*D) = (B, N, 3, H, D)
+        else:
+            qkv = ops.gemm(h, wqh, 'nt', bias=bq)
         q5 = qkv.view(B, N, 3, H, D)
         o, lse = ops.attn_fwd(q5[:, :, 0], q5[:, :, 1], q5[:, :, 2], lengths, window)  # padded query rows come back zero
         y = ops.gemm(o.view(B * N, H * D), woh, 'nt', bias=bout, resid=x if residual else None, out_dtype=F32)

@@ -110,6 +110,21 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
     return (c, pre) if save_pre else c
 
 
+def gemm_qkv_rotary(x: torch.Tensor, w_regrouped: torch.Tensor, bias: Optional[torch.Tensor], cos: torch.Tensor, sin: torch.Tensor,
+                    N: int, H: int, D: int) -> torch.Tensor:
+    """qkv projection + NeoX rotary in one launch: x (M, K) bf16, w_regrouped (3 H D, K) bf16 with rows [q | k | v] (bias regrouped
+    alike, f32) -> (M, 3 H D) bf16 = (B, N, 3, H, D) with q, k rotated for position (row % N); cos / sin (N, D/2) f32."""
+    _chk(x, 'x', torch.bfloat16); _chk(w_regrouped, 'w', torch.bfloat16); _chk(cos, 'cos', torch.float32); _chk(sin, 'sin', torch.float32)
+    M, K = x.shape
+    if tuple(w_regrouped.shape) != (3 * H * D, K): raise ValueError('gemm_qkv_rotary: weight shape')
+    if tuple(cos.shape) != (N, D // 2) or tuple(sin.shape) != (N, D // 2): raise ValueError('gemm_qkv_rotary: rotary tables must be (N, D/2)')
+    if bias is not None: _chk(bias, 'bias', torch.float32)
+    out = torch.empty(M, 3 * H * D, dtype=torch.bfloat16, device=x.device)
+    _lib.call('sconf_gemm_qkv_rotary', _p(x), _p(w_regrouped), _p(out), M, K, H, D, x.stride(0), w_regrouped.stride(0), _p(bias),
+              _p(cos), _p(sin), N, _stream())
+    return out
+
+
 def pick_split_k(M: int, N: int, K: int, n_cus: int = 256) -> int:
     """Split-K factor for weight-gradient GEMMs (few output tiles, very long K).
 

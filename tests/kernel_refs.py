@@ -169,6 +169,20 @@ def rotary_qkv_bwd(dq, dk, dv, cos, sin, B, N, H, D):
     return torch.stack([dq, dk, dv], dim=-1).reshape(B * N, H * D * 3).to(torch.bfloat16)
 
 
+def gemm_qkv_rotary(x, w_regrouped, bias, cos, sin, N, H, D):
+    """f32 product, rotation on the f32 result, ONE rounding to bf16 (the fused epilogue's rounding points)."""
+    y = x.to(f32) @ w_regrouped.to(f32).t()
+    if bias is not None: y = y + bias
+    M = y.shape[0]
+    y5 = y.view(M // N, N, 3, H, D).clone()
+    c, s_ = cos.view(1, N, 1, D // 2), sin.view(1, N, 1, D // 2)
+    for w in (0, 1):
+        a, b = y5[:, :, w, :, :D // 2].clone(), y5[:, :, w, :, D // 2:].clone()
+        y5[:, :, w, :, :D // 2] = a * c - b * s_
+        y5[:, :, w, :, D // 2:] = b * c + a * s_
+    return y5.view(M, 3 * H * D).to(torch.bfloat16)
+
+
 def rotary_inplace_(qkv, cos, sin, B, N, H, D):
     t = qkv.view(B, N, 3, H, D)
     t[:, :, 0] = _rot(t[:, :, 0].to(f32), cos, sin).to(qkv.dtype)

@@ -245,6 +245,30 @@ def test_norm2_fwd_bwd(ops, d, twice):
         assert torch.equal(dx_only, dx)
 
 
+@pytest.mark.parametrize('Bn,N,H,K,bias', [(2, 256, 2, 768, False), (4, 128, 6, 256, True), (1, 64, 4, 64, False)])
+def test_gemm_qkv_rotary(ops, Bn, N, H, K, bias, monkeypatch):
+    """qkv projection with the rotary rotation in the GEMM epilogue (256x256 kernel, head_dim 128; the last shape does not fit that
+    kernel and takes the GEMM + in-place path): against the two-launch path on the device and the f32 reference."""
+    import sys
+    sys.path.insert(0, '.')
+    from oracle.sconformer_ref import rotary_tables
+    D = 128
+    M = Bn * N
+    cos, sin = rotary_tables(N, D, 1.5e6)
+    cos, sin = dev(cos[:, :D // 2].contiguous()), dev(sin[:, :D // 2].contiguous())
+    x = dev(rnd(M, K, seed=1)); w = dev(rnd(3 * H * D, K, seed=2) * 0.1)
+    b = dev(rnd(3 * H * D, dtype=F32, seed=3)) if bias else None
+    got = ops.gemm_qkv_rotary(x, w, b, cos, sin, N, H, D)
+    two = ops.rotary_inplace_(ops.gemm(x, w, 'nt', bias=b), cos, sin, Bn, N, H, D)
+    ref = R.gemm_qkv_rotary(x.cpu(), w.cpu(), None if b is None else b.cpu(), cos.cpu(), sin.cpu(), N, H, D)
+    close(got, ref, name='qkv + rotary epilogue vs f32 reference')
+    close(got, two.cpu(), name='qkv + rotary epilogue vs GEMM + in-place rotary', tol=1.6e-2)       # the in-place path rounds to bf16 twice
+    v_cols = slice(2 * H * D, 3 * H * D)
+    assert torch.equal(got[:, v_cols], two[:, v_cols])                                              # the v block is not rotated
+    monkeypatch.setenv('SCONF_QKV_ROT_EPILOGUE_OFF', '1')                                            # the fallback inside the entry point
+    assert torch.equal(ops.gemm_qkv_rotary(x, w, b, cos, sin, N, H, D), two)
+
+
 # ------------------------------------------------------------------------------------------------ elementwise
 def test_cast(ops):
     x = rnd(1000003, dtype=F32)
