@@ -14,9 +14,9 @@ def t(fn, n=8):
         e1.record(); torch.cuda.synchronize()
         best = min(best, e0.elapsed_time(e1) / n)
     return best
-M = 131072
+M = int(os.environ.get("BLAS_M", "262144"))
 print('NT  y = x W^T (bf16 out)')
-for n, k in [(3072, 768), (768, 3072), (2304, 768), (768, 768), (4096, 768), (768, 4096)]:
+for n, k in [(3072, 768), (768, 3072), (2304, 768), (768, 768), (4096, 768), (768, 4096), (768, 2304), (1536, 768), (768, 1536)]:
     x = torch.randn(M, k, device='cuda').bfloat16(); w = torch.randn(n, k, device='cuda').bfloat16()
     a = t(lambda: ops.gemm(x, w, 'nt')); b = t(lambda: torch.nn.functional.linear(x, w))
     print(f'  {M}x{n}x{k}: sconf {2.0*M*n*k/a/1e9:5.0f} TF   blas {2.0*M*n*k/b/1e9:5.0f} TF', flush=True)
