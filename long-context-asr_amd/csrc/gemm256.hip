@@ -733,8 +733,8 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
 
 // Tile width for the NT layout: fewest "rounds x width" over the CUs (ties -> the wider tile); 0 = not eligible.
 static int pick_width(const GemmParams& p, int layout, int cus) {
+    if (p.M % TM || p.K % TK || p.k_per_split % TK) return 0;                 // whole tiles only: the kernels floor M / TM and K / TK
     if (p.rot_cos) return (layout == 0 && p.N % 256 == 0) ? 256 : 0;          // the rotary epilogue exists for the 256-wide tile
-    if (p.M % TM || p.K % TK || p.k_per_split % TK) return 0;
     if (const char* e = getenv("SCONF_GEMM_256_WIDTH")) {                 // benchmarking override
         const int w = atoi(e);
         return ((w == 256 || (w == 192 && layout == 0)) && p.N % w == 0) ? w : 0;

@@ -31,7 +31,9 @@ BF16, F32 = torch.bfloat16, torch.float32
 # forward) re-derives ALL of them from the masters in one kernel launch.  Module-level calls (layer.ff1(x), decoder(x), ...)
 # do not pass through the model forward, so every shadow also remembers the state of its master when it was cast - the
 # tensor's version counter plus an epoch that the fused optimiser bumps (its kernel writes the parameters behind autograd's
-# back) - and `wcast` / `wcast_t` re-cast a shadow whose master has moved on: a shadow can never be older than its use.
+# back) - and `wcast` / `wcast_t` re-cast a shadow whose master has moved on.  What the check cannot see is a write through
+# `.data` (no version bump): whoever does that calls `bump_weight_epoch()` (parallel.broadcast_module_state does) or
+# `clear_weight_cache()`; a model forward re-casts everything regardless.
 class _Shadow:
     __slots__ = ('w', 'rows', 'cols', 'n', 't', 'vn', 'vt', 'regroup')
 
@@ -55,6 +57,14 @@ def bump_weight_epoch() -> None:
 
 def _state(e: _Shadow):
     return (e.w._version, _epoch[0])
+
+
+def forget_weight_shadows(*ws: torch.Tensor) -> None:
+    """Drop the shadows of temporaries that stood in for parameters during one forward (the class-padded decoder weights of a
+    vocabulary that is not a multiple of 16): they would otherwise be kept alive, and re-cast, for ever."""
+    for w in ws:
+        for rg in (False, True):
+            _shadows.pop((w.data_ptr(), tuple(w.shape), rg), None)
 
 
 def clear_weight_cache() -> None:
@@ -158,7 +168,7 @@ class _G:
         if p is None:
             self.direct, self.t = False, None
             return
-        g = p.grad
+        g = p.grad if p.is_leaf else None                # (a non-leaf stands in for a parameter: the class-padded decoder weights)
         self.direct = bool(_direct['on'] and g is not None and g.dtype == F32 and g.is_contiguous() and g.shape == p.shape)
         shape = tuple(p.shape) if shape is None else tuple(shape)
         self.t = g.view(shape) if self.direct else torch.zeros(shape, dtype=F32, device=p.device)
@@ -282,7 +292,8 @@ class Norm2Fn(Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, eps1: float, eps2: float, twice: bool):
-        x = x.contiguous()
+        ctx.set_materialize_grads(False)                  # an unused output's gradient arrives as None, not as an (M, d) zero tensor:
+        x = x.contiguous()                                # the last layer's y1 (the head takes h2 only) is 0.8 GB at the bench shape
         y1, h2, st = ops.norm2_fwd(x, w1, b1, w2, b2, eps1, eps2, twice)
         ctx.save_for_backward(x, w1, b1, w2, b2, *st)
         ctx.P, ctx.eps1 = (w1, b1, w2, b2), eps1
@@ -294,6 +305,8 @@ class Norm2Fn(Function):
         x, w1, b1, w2, b2 = sv[:5]
         st = tuple(sv[5:])
         pw1, pb1, pw2, pb2 = ctx.P
+        if dy1 is None and dh2 is None:
+            return (None,) * 8
         dw1, db1 = _G(pw1), _G(pb1)
         if dh2 is None:                                   # h2 was not used: this is norm_out alone
             dx, dx16, cs = ops.norm_bwd(dy1.contiguous(), x, w1, st[0], st[1], 'layer_norm', ctx.eps1, None, F32, dw1.t, db1.t, twin=True)
@@ -664,10 +677,12 @@ class HeadCTCFn(Function):
         return (g, None, dnw.out(), dnb.out(), dwf, dbf) + (None,) * 8
 
 
-def decoder_head_ctc(x, nw, nb, wff, bff, B, targets, input_lengths, target_lengths, blank, n_norms=1, mode='layer_norm', eps=1e-5, prenormed=None):
-    """(B,) CTC negative log-likelihoods of the head applied to x (B N, d); integer tensors as for ctc_nll."""
+def decoder_head_ctc(x, nw, nb, wff, bff, B, targets, input_lengths, target_lengths, blank, n_norms=1, mode='layer_norm', eps=1e-5, prenormed=None,
+                     num_labels=None):
+    """(B,) CTC negative log-likelihoods of the head applied to x (B N, d); integer tensors as for ctc_nll.
+    num_labels: the number of real classes when wff carries padding rows (labels must stay below it)."""
     dev = x.device
-    _check_ctc_host_args(targets, input_lengths, target_lengths, x.shape[0] // max(B, 1), wff.shape[0])
+    _check_ctc_host_args(targets, input_lengths, target_lengths, x.shape[0] // max(B, 1), wff.shape[0] if num_labels is None else num_labels)
     tg = targets.to(device=dev, dtype=torch.int32).contiguous()
     il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()
@@ -763,6 +778,8 @@ def ctc_nll(log_probs_bnc, targets, input_lengths, target_lengths, blank: int) -
     dev = log_probs_bnc.device
     _B, _N, _C = log_probs_bnc.shape
     _check_ctc_host_args(targets, input_lengths, target_lengths, _N, _C)
+    if _C % 4:                                            # the kernels move 4 classes per access: pad with impossible classes (p = 0)
+        log_probs_bnc = torch.nn.functional.pad(log_probs_bnc, (0, 4 - _C % 4), value=-1e30)
     tg = targets.to(device=dev, dtype=torch.int32).contiguous()
     il = input_lengths.to(device=dev, dtype=torch.int32).contiguous()
     tl = target_lengths.to(device=dev, dtype=torch.int32).contiguous()

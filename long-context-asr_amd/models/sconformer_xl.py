@@ -112,6 +112,7 @@ class SCConformerXL(BaseModel):
 
         extra = 1 if self.legasee_double_norm else 0
         h = None
+        dec.hold_padded()                                             # class padding for vocab_size + 1 not a multiple of 16 (no-op otherwise)
         for lth, layer in enumerate(self.layers):
             last = lth == len(self.layers) - 1
             sc = not last and self.self_conditioning
@@ -137,6 +138,7 @@ class SCConformerXL(BaseModel):
                    'ctc_nll': dec.ctc_nll(x, ctc_targets[0], length, ctc_targets[1], extra_norms=extra, prenormed=h)}
         else:
             out = {'final_posteriors': dec(x, logits=return_logits, extra_norms=extra, prenormed=h), 'length': length}
+        dec.release_padded()
         if self.training and self.rotary_pos_emb is not None:
             self.rotary_pos_emb.reset_if_needed()
         return out

@@ -17,10 +17,19 @@ import torch
 import torch.distributed as dist
 
 
-def broadcast_module_state(module: torch.nn.Module, src: int = 0) -> None:
-    """Make parameters and buffers (BatchRenorm running stats) identical on every rank."""
+def broadcast_module_state(module: torch.nn.Module, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Make parameters and buffers (BatchRenorm running stats) identical on every rank.  The writes go through `.data`, which
+    autograd's version counters do not see: the bf16 weight shadows are told explicitly (functional.bump_weight_epoch)."""
+    from . import functional as Fn
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src)
+        dist.broadcast(t.data, src, group=group)
+    Fn.bump_weight_epoch()
+
+
+def broadcast_module_buffers(module: torch.nn.Module, src: int = 0, group: Optional[dist.ProcessGroup] = None) -> None:
+    """Buffers only (BatchRenorm running_mean / running_std / num_batches_tracked): rank `src` is authoritative."""
+    for t in module.buffers():
+        dist.broadcast(t.data, src, group=group)
 
 
 class GradSync:

@@ -72,7 +72,8 @@ class Trainer:
     def step_without_data(self):
         """This rank has nothing to train in a step the other ranks do take (its recordings have run out): contribute zero
         gradients to the same all-reduces and apply the same optimiser step, so that every rank issues the same collectives and
-        the replicas stay identical."""
+        the PARAMETERS stay identical.  BatchRenorm buffers do not move on this rank (no forward ran): `train_recording` re-broadcasts
+        rank 0's buffers after a batch of recordings with unequal participation."""
         self.sync.finish()
         self.opt.step(max_norm=self.clip_value)
         self.opt.zero_grad()
@@ -89,36 +90,52 @@ class Trainer:
         plan = plan_chunks(chunk_spectogram(audio, chunk_size, chunk_overlap), audio_lengths, chunk_overlap)
         world = self.sync.world
         nominal = audio.shape[0] * world
-        n_chunks = len(plan)
+        # what this rank can train on, chunk by chunk (audio stays a view until its step)
+        works = []
+        for ix, c in enumerate(plan):
+            work = None
+            keep = c['audio_lengths'] > 0                       # an exactly exhausted recording: the reference feeds a zero-length
+            if not bool(keep.all()):                            # row and lands in its NaN-skip branch; here the row is dropped
+                c = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in c.items()}
+            if c['audio'].shape[0] > 0:
+                tg, tl = targets_for_chunk(ix, c)
+                if int(tl.max()) > 0:                           # train.py:186-187: nothing to align in this chunk -> skipped
+                    work = (c['audio'], c['audio_lengths'], tg, tl)
+            works.append(work)
+        n_chunks = len(works)
+        ranks_with_work = None
         if world > 1:
             # The reference has no data parallelism; here every optimiser step is a set of collectives, so all ranks must take
-            # the same number of steps although their recordings differ in length: agree on the longest plan, and per chunk on
-            # whether ANY rank has something to train (a rank that has not runs `step_without_data`).
+            # the same number of steps although their recordings differ in length: agree ONCE per recording batch on the longest
+            # plan (MAX) and on how many ranks have something to train in each chunk (SUM of the whole flag vector) - two host
+            # syncs per batch of recordings instead of two per chunk.  A rank without work in a chunk another rank trains on
+            # runs `step_without_data`.
             t = torch.tensor([n_chunks], dtype=torch.int64, device=audio.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.sync.group)
             n_chunks = int(t)
+            flags = torch.zeros(n_chunks, dtype=torch.int64, device=audio.device)
+            if works:
+                flags[:len(works)] = torch.tensor([int(w is not None) for w in works], dtype=torch.int64, device=audio.device)
+            dist.all_reduce(flags, op=dist.ReduceOp.SUM, group=self.sync.group)
+            ranks_with_work = flags.tolist()
         losses = []
         for ix in range(n_chunks):
-            work = None
-            if ix < len(plan):
-                c = plan[ix]
-                keep = c['audio_lengths'] > 0                   # an exactly exhausted recording: the reference feeds a zero-length
-                if not bool(keep.all()):                        # row and lands in its NaN-skip branch; here the row is dropped
-                    c = {k: (v[keep] if torch.is_tensor(v) and v.shape[:1] == keep.shape else v) for k, v in c.items()}
-                if c['audio'].shape[0] > 0:
-                    tg, tl = targets_for_chunk(ix, c)
-                    if int(tl.max()) > 0:                       # train.py:186-187: nothing to align in this chunk -> skipped
-                        work = (c['audio'].contiguous(), c['audio_lengths'], tg, tl)
+            work = works[ix] if ix < len(works) else None
             if world > 1:
-                t = torch.tensor([int(work is not None)], dtype=torch.int64, device=audio.device)
-                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.sync.group)
-                if int(t) == 0:
+                if ranks_with_work[ix] == 0:
                     continue                                    # no rank has work: everyone skips together
                 if work is None:
                     self.step_without_data()
                     continue
             elif work is None:
                 continue
-            losses.append(self.step(*work, norm_frames=chunk_size, norm_batch=nominal))
+            losses.append(self.step(work[0].contiguous(), *work[1:], norm_frames=chunk_size, norm_batch=nominal))
+        if world > 1 and any(0 < n < world for n in ranks_with_work):
+            # Ranks that sat a step out did not run its forward, so their BatchRenorm running statistics (and step counters, on
+            # which the rmax / dmax ramps depend) have fallen behind.  Rank 0's buffers are authoritative - what DistributedDataParallel
+            # does on every forward (broadcast_buffers) - and are re-broadcast whenever participation was unequal, so the replicas
+            # (and whichever rank writes the checkpoint) stay identical.
+            from .parallel import broadcast_module_buffers
+            broadcast_module_buffers(self.model, 0, self.sync.group)
         return losses
 

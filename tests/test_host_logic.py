@@ -379,10 +379,63 @@ def test_madgrad_skipped_step_does_not_advance_k_and_frozen_parameters_are_left_
     assert opt2.k == 1 and torch.equal(opt2.param_groups[0]['_s'], opt.param_groups[0]['_s'])
 
 
-def test_decoder_refuses_class_counts_the_kernels_cannot_take():
-    """vocab_size + 1 must be a multiple of 16 on the HIP path; the constructor says so (the reference default
-    vocab_size=128 gives 129 classes)."""
+def _run_129_class_step(device, fused_loss):
+    """One training step of a tiny model at the reference's DEFAULT vocabulary (vocab_size=128 -> 129 classes, sconformer_xl.py:34),
+    which the kernels only take padded to 144, against the oracle on the same weights."""
+    from oracle import sconformer_ref as O
+    from lcasr_amd.losses import CTCLoss
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    cfg = dict(vocab_size=128, n_layers=2, d_model=64, n_heads=2, head_dim=32, subsampling_conv_channels=32, use_rotary=True,
+               rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True, bias_in_ff=False, default_norm='layer_norm')
+    torch.manual_seed(1)                           # (seed 12345 draws a near-degenerate BatchRenorm channel at this shape: bf16 noise 0.28 in
+    model = SCConformerXL(**cfg)                   # layer 0's gradients with or without padding; seeds 1 / 2 / 3 give 0.07 / 0.12 / 0.07)
+    assert model.decoder.num_classes == 129 and model.decoder.padded_classes == 144
+    assert tuple(model.decoder.ff.weight.shape) == (129, 64) and tuple(model.decoder.reprojection.weight.shape) == (64, 129)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 80, 256, generator=g)
+    lengths = torch.tensor([256, 200])
+    targets = torch.randint(0, 128, (2, 8), generator=g)
+    targets[0, 0] = 127                                                        # the last real label, next to the blank (128)
+    tl = torch.tensor([8, 6])
+    sdr = {k: v.clone().requires_grad_(v.is_floating_point()) for k, v in sd.items()}
+    ref_loss, ref_scaled, ref_out = O.train_step_loss(sdr, O.make_config(**cfg), x, lengths, targets, tl)
+    ref_scaled.backward()
+    model = model.to(device).train()
+    if fused_loss:
+        out = model(x.to(device), length=lengths.to(device), ctc_targets=(targets.to(device), tl.to(device)))
+        loss, lp = out['ctc_nll'].sum(), None
+    else:
+        out = model(x.to(device), length=lengths.to(device))
+        lp = out['final_posteriors']
+        assert tuple(lp.shape) == (2, 32, 129) and lp.is_contiguous()
+        loss = CTCLoss(blank=128, reduction='sum')(lp.transpose(0, 1), targets.to(device), out['length'], tl.to(device))
+    (loss / (256 * 2) * 100).backward()
+    from lcasr_amd import functional as Fn
+    assert model.decoder._held is None and not any(k[1] in ((144, 64), (64, 144), (144,)) for k in Fn._shadows), 'padded stand-ins were not released'
+    grads = {k: p.grad.detach().float().cpu() for k, p in model.named_parameters()}
+    ref_grads = {k: sdr[k].grad for k in grads}
+    return float(loss.detach()), float(ref_loss.detach()), None if lp is None else lp.detach(), ref_out['final_posteriors'].detach(), grads, ref_grads
+
+
+@pytest.mark.parametrize('fused_loss', [False, True])
+def test_reference_default_vocabulary_129_classes_is_padded_not_refused(emulated_ops, fused_loss):
+    """SCConformerXL() with the reference's defaults constructs (round 2 raised a ValueError for 129 classes);
+    the class dimension is padded inside the decoder and the padding is invisible: shapes, loss, log-probs and every gradient
+    against the oracle (CPU, emulated ops - the GPU twin is in test_model_gpu.py)."""
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
     from lcasr_amd.components.decoder import ASRLinearSCDecoder
-    with pytest.raises(ValueError, match='multiple of 16'):
-        ASRLinearSCDecoder(d_model=64, vocab_size=128)
-    assert ASRLinearSCDecoder(d_model=64, vocab_size=127).num_classes == 128
+    assert ASRLinearSCDecoder(d_model=64, vocab_size=127).padded_classes == 128
+    torch.manual_seed(0)
+    assert SCConformerXL(n_layers=1).decoder.num_classes == 129                # the reference's default constructor
+    loss, ref_loss, lp, ref_lp, grads, ref_grads = _run_129_class_step('cpu', fused_loss)
+    assert abs(loss - ref_loss) / ref_loss < 2e-3
+    if lp is not None:
+        d = (lp.float() - ref_lp).abs()
+        assert float(d.mean()) < 0.05 and float(d.max()) < 0.35
+    from common_model import rel_l2_errors
+    errs = rel_l2_errors(grads, ref_grads)
+    worst = max(errs, key=errs.get)
+    assert errs[worst] < 0.15, (worst, errs[worst])
+    for k in ('decoder.ff.weight', 'decoder.ff.bias', 'decoder.reprojection.weight'):
+        assert grads[k].shape == ref_grads[k].shape and errs[k] < 0.1, (k, errs[k])

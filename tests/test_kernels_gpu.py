@@ -245,10 +245,15 @@ def test_norm2_fwd_bwd(ops, d, twice):
         assert torch.equal(dx_only, dx)
 
 
-@pytest.mark.parametrize('Bn,N,H,K,bias', [(2, 256, 2, 768, False), (4, 128, 6, 256, True), (1, 64, 4, 64, False)])
-def test_gemm_qkv_rotary(ops, Bn, N, H, K, bias, monkeypatch):
-    """qkv projection with the rotary rotation in the GEMM epilogue (256x256 kernel, head_dim 128; the last shape does not fit that
-    kernel and takes the GEMM + in-place path): against the two-launch path on the device and the f32 reference."""
+@pytest.mark.parametrize('Bn,N,H,K,bias,epilogue', [(2, 256, 2, 768, False, False), (4, 128, 6, 256, True, False), (1, 64, 4, 64, False, False),
+                                                     (32, 256, 6, 768, False, True), (32, 256, 6, 768, True, True), (16, 512, 6, 768, False, True),
+                                                     (3, 2047, 6, 768, False, False), (3, 2048, 6, 776, True, False)])
+def test_gemm_qkv_rotary(ops, Bn, N, H, K, bias, epilogue, monkeypatch):
+    """qkv projection with the rotary rotation in the GEMM epilogue (256x256 kernel, head_dim 128): against the two-launch path on the
+    device and the f32 reference.  `epilogue` = the shape is taken by the 256-row kernel (enough whole tiles to fill the chip): the
+    result then differs from the two-launch one by a bf16 rounding, which is how the test knows the epilogue ran.  The small shapes and
+    the two last ones (M or K not whole tiles: rows / a K tail the 256-row kernel would silently drop) must take the GEMM + in-place
+    rotary path inside the entry point and equal it bit for bit."""
     import sys
     sys.path.insert(0, '.')
     from oracle.sconformer_ref import rotary_tables
@@ -265,6 +270,7 @@ def test_gemm_qkv_rotary(ops, Bn, N, H, K, bias, monkeypatch):
     close(got, two.cpu(), name='qkv + rotary epilogue vs GEMM + in-place rotary', tol=1.6e-2)       # the in-place path rounds to bf16 twice
     v_cols = slice(2 * H * D, 3 * H * D)
     assert torch.equal(got[:, v_cols], two[:, v_cols])                                              # the v block is not rotated
+    assert torch.equal(got, two) != epilogue, 'rotary epilogue taken' if not epilogue else 'rotary epilogue NOT taken'
     monkeypatch.setenv('SCONF_QKV_ROT_EPILOGUE_OFF', '1')                                            # the fallback inside the entry point
     assert torch.equal(ops.gemm_qkv_rotary(x, w, b, cos, sin, N, H, D), two)
 

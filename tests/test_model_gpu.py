@@ -589,3 +589,20 @@ def test_ctc_rejects_or_poisons_invalid_arguments():
         assert torch.isnan(nll[1]) and torch.equal(nll[[0, 2]], ok[[0, 2]])
         gr, = torch.autograd.grad(nll[[0, 2]].sum() + nll[1], lp)
         assert torch.isnan(gr[1, :30]).all() and torch.isfinite(gr[0]).all() and torch.isfinite(gr[2]).all()
+
+
+@pytest.mark.parametrize('fused_loss', [False, True])
+def test_reference_default_vocabulary_129_classes_on_the_device(fused_loss):
+    """the reference's default vocab_size=128 (129 classes, sconformer_xl.py:34) runs on the HIP path with the class
+    dimension padded to 144 inside the decoder (zero weight rows, -1e30 bias): output shapes are the reference's, loss, log-probs
+    and every gradient match the oracle on the same weights (the CPU twin with emulated ops is in test_host_logic.py)."""
+    from test_host_logic import _run_129_class_step
+    loss, ref_loss, lp, ref_lp, grads, ref_grads = _run_129_class_step('cuda', fused_loss)
+    torch.cuda.synchronize()
+    assert abs(loss - ref_loss) / ref_loss < 2e-3, (loss, ref_loss)
+    if lp is not None:
+        d = (lp.float().cpu() - ref_lp).abs()
+        assert float(d.mean()) < 0.05 and float(d.max()) < 0.35, (float(d.mean()), float(d.max()))
+    errs = rel_l2_errors(grads, ref_grads)
+    _report(f'129 classes (fused_loss={fused_loss})', errs)
+    assert max(errs.values()) < GRAD_L2_WORST, sorted(errs.items(), key=lambda kv: -kv[1])[:5]
