@@ -166,11 +166,14 @@ int sconf_sub_silu_transpose(int bwd, const void* pre, const void* ds, void* out
                              sconf_stream_t stream);
 
 /* CTC, torch.nn.CTCLoss(blank, reduction='sum') on the (N,B,C) view (exp/train.py:104,249); batch-major input.
- * lpg/alpha/beta: f32 [B][N][2*Smax+1] workspaces; nll: f32 [B]; grad_out: f32 [B] or NULL. */
+ * lpg/alpha/beta: f32 [B][N][2*Smax+1] workspaces; nll: f32 [B]; grad_out: f32 [B] or NULL.
+ * offs: f64 [2*B*N + B] workspace written by the forward and read by the backward: alpha and beta rows are stored relative to a
+ * per-frame offset (kept in f64, together with the f64 nll), which keeps the f32 lattice exact to ~1e-4 at 16384 frames where the
+ * plain log-space recursion (and torch's own f32 op) is 24 % off in the gradient. */
 int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
-                  const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll, int64_t B, int64_t N,
+                  const int32_t* target_lengths, float* lpg, float* alpha, float* beta, double* offs, float* nll, int64_t B, int64_t N,
                   int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
-int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const float* nll,
+int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const double* offs, const float* nll,
                   const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths, const float* grad_out,
                   float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
 /* The same loss taken from the decoder's LOGITS (f32 (B,N,C)): decoder.py:25 F.log_softmax + torch.nn.CTCLoss (exp/train.py:104,249)
@@ -179,12 +182,12 @@ int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, 
  * into colsum_out [C] (the decoder bias gradient; needs sconf_ctc_bwd_logits_workspace(B*N, C) floats of scratch).  Neither the
  * log-probabilities nor their gradient exist as (B,N,C) tensors. */
 int sconf_ctc_fwd_logits(const float* logits, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
-                         float* lse, float* lpg, float* alpha, float* beta, float* nll,
+                         float* lse, float* lpg, float* alpha, float* beta, double* offs, float* nll,
                          int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
 int64_t sconf_ctc_bwd_logits_workspace(int64_t rows, int64_t C);
 int sconf_ctc_bwd_logits(const float* logits, const float* lse, const float* lpg, const float* alpha, const float* beta,
-                         const float* nll, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
-                         const float* grad_out, void* dlogits_bf16, float* colsum_out, float* workspace,
+                         const double* offs, const float* nll, const int32_t* targets, const int32_t* input_lengths,
+                         const int32_t* target_lengths, const float* grad_out, void* dlogits_bf16, float* colsum_out, float* workspace,
                          int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, sconf_stream_t stream);
 
 

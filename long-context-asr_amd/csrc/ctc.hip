@@ -7,6 +7,14 @@
 //   2. alpha/beta  one workgroup per (sample, direction): 2B workgroups run concurrently; the lattice row lives
 //                  in LDS (double-buffered, one barrier per step); lpg rows are prefetched 4 steps ahead into
 //                  registers so the serial chain never waits on HBM.  beta is alpha on the mirrored lattice.
+//                  The rows are stored RENORMALISED (round 3): row t holds alpha_t - A_t, where A_t (f64, one scalar per frame,
+//                  `offs`) accumulates the maximum of every previous stored row.  Plain log-space f32 rows reach |alpha| ~ 1e5 at
+//                  16384 frames (the 131072-frame context): one ulp is 0.008 there and the roundings of the serial chain
+//                  random-walk to a 0.4-0.5 drift of the per-frame gradient sums and a 0.24 relative L2 error of the gradient
+//                  against an f64 lattice - torch's own f32 op has exactly that error (measured).  Renormalised rows stay within
+//                  a few tens of the origin (ulp ~1e-6), the large parts cancel in f64 once per frame (A_t + B_t + nll), and the
+//                  row maximum costs no barrier: wave maxima are published in LDS in front of the step's own barrier and applied
+//                  one step late (any offset sequence is exact; it only has to keep the magnitudes small).
 //   3. grad     one workgroup per (b,t) row: occupancy scattered into an LDS histogram over classes, then
 //               grad = g * (exp(lp) - occupancy)   [ATen convention; zero for t >= input_length].
 #include "common.h"
@@ -80,23 +88,28 @@ template <int MAXS>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ targets,
                                                              const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                              float* __restrict__ alpha, float* __restrict__ beta,
-                                                             float* __restrict__ nll, int B, int N, int C, int Smax, int Lmax, int blank) {
-    extern __shared__ float lat[];                      // [2][Lmax + 2], two leading -inf guard cells per row
+                                                             float* __restrict__ nll, double* __restrict__ offs,
+                                                             int B, int N, int C, int Smax, int Lmax, int blank) {
+    extern __shared__ float lat[];                      // [2][Lmax + 2], two leading -inf guard cells per row; then [2][16] wave maxima
     const int b = blockIdx.x % B;
     const bool is_beta = blockIdx.x >= B;
     const int T = in_len[b], S = tg_len[b], L = 2 * S + 1;
     float* out = (is_beta ? beta : alpha) + (long)b * N * Lmax;
+    double* off_out = offs + ((long)(is_beta ? B : 0) + b) * N;     // [alpha offsets (B,N) | beta offsets (B,N) | nll in f64 (B)]
+    double* nll64 = offs + 2L * B * N;
     const float* lg = lpg + (long)b * N * Lmax;
     const int nt = blockDim.x, tid = threadIdx.x;
     const int W = Lmax + 2;
-    if (T <= 0) { if (!is_beta && tid == 0) nll[b] = INFINITY; return; }
+    float* wm = lat + 2 * W;                            // [2][16] per-wave maxima of the row just written
+    const int nw = nt >> 6, wave = tid >> 6;
+    if (T <= 0) { if (!is_beta && tid == 0) { nll[b] = INFINITY; nll64[b] = INFINITY; } return; }
     // Inputs torch.nn.CTCLoss rejects on the host (input_length > N, target_length > Smax, a label outside [0, C)): the lengths
     // live on the device here, so the sample is poisoned instead - nll = NaN, its gradient rows NaN (ctc_grad_kernel), which the
     // optimiser's non-finite check turns into a skipped step - and nothing is indexed with the bad value.
     {
         int bad = (T > N) | (S < 0) | (S > Smax);
         if (!bad) for (int i = tid; i < S; i += nt) { const int lab = targets[(long)b * Smax + i]; bad |= (lab < 0) | (lab >= C); }
-        if (__syncthreads_or(bad)) { if (!is_beta && tid == 0) nll[b] = NAN; return; }
+        if (__syncthreads_or(bad)) { if (!is_beta && tid == 0) { nll[b] = NAN; nll64[b] = NAN; } return; }
     }
 
     // per-state constants in MIRRORED coordinates sp (beta walks the reversed lattice)
@@ -131,6 +144,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
         }
     };
     load_group(pf, 0);
+    double A = 0.0;                                      // sum of the offsets subtracted so far (kept by thread 0)
     for (int i0 = 0; i0 < T; i0 += 4) {
         load_group(nx, i0 + 4);                          // prefetch the next 4 time steps
 #pragma unroll
@@ -140,17 +154,30 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 const int t = is_beta ? T - 1 - i : i;
                 float* cur = lat + (i & 1) * W + 2;
                 const float* prev = lat + ((i & 1) ^ 1) * W + 2;
+                // this step's offset: the maximum of the previous STORED row (its wave maxima were published before the barrier)
+                float c = 0.f;
+                if (i > 0) {
+                    const float* pm = wm + ((i & 1) ^ 1) * 16;
+                    float m = pm[0];
+                    for (int w = 1; w < nw; ++w) m = fmaxf(m, pm[w]);
+                    c = (m == -INFINITY) ? 0.f : m;
+                }
+                if (tid == 0) { A += (double)c; off_out[t] = A; }
+                float mine = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < MAXS; ++k) {
                     const int sp = tid + k * nt;
                     if (sp < L) {
                         float v;
                         if (i == 0) v = (sp < 2) ? pf[j][k] : -INFINITY;
-                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : -INFINITY) + pf[j][k];
+                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : -INFINITY) + (pf[j][k] - c);
                         cur[sp] = v;
                         out[(long)t * Lmax + (is_beta ? L - 1 - sp : sp)] = v;
+                        mine = fmaxf(mine, v);
                     }
                 }
+                mine = wave_max(mine);
+                if ((tid & 63) == 0) wm[(i & 1) * 16 + wave] = mine;
                 __syncthreads();
             }
         }
@@ -161,16 +188,19 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     }
     if (!is_beta && tid == 0) {
         const float* last = lat + ((T - 1) & 1) * W + 2;
-        nll[b] = -lse3(last[L - 1], L > 1 ? last[L - 2] : -INFINITY, -INFINITY);
+        const double v = -(A + (double)lse3(last[L - 1], L > 1 ? last[L - 2] : -INFINITY, -INFINITY));
+        nll64[b] = v;
+        nll[b] = (float)v;
     }
 }
 
 __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__ lp, const float* __restrict__ lpg,
                                                        const float* __restrict__ alpha, const float* __restrict__ beta,
-                                                       const float* __restrict__ nll, const int* __restrict__ targets,
+                                                       const float* __restrict__ nll, const double* __restrict__ offs,
+                                                       const int* __restrict__ targets,
                                                        const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                        const float* __restrict__ grad_out, float* __restrict__ grad,
-                                                       int N, int C, int Smax, int Lmax, int blank) {
+                                                       int B, int N, int C, int Smax, int Lmax, int blank) {
     extern __shared__ float occ[];                      // [C]
     const long bt = blockIdx.x;
     const int b = (int)(bt / N), t = (int)(bt % N);
@@ -191,9 +221,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
     __syncthreads();
     const int L = 2 * tg_len[b] + 1;
     const long base = bt * Lmax;
+    // alpha, beta are stored relative to their per-frame offsets: the large parts cancel here, once per frame, in f64
+    const float adj = (float)(offs[bt] + offs[(long)B * N + bt] + offs[2L * B * N + b]);
     for (int s = threadIdx.x; s < L; s += 256) {
         const int lab = (s & 1) ? targets[(long)b * Smax + (s >> 1)] : blank;
-        atomicAdd(&occ[lab], __expf(alpha[base + s] + beta[base + s] + nl - lpg[base + s]));
+        atomicAdd(&occ[lab], __expf(alpha[base + s] + beta[base + s] - lpg[base + s] + adj));
     }
     __syncthreads();
     const float g = grad_out ? grad_out[b] : 1.f;          // per-sample upstream gradient
@@ -213,10 +245,11 @@ __global__ __launch_bounds__(256) void ctc_grad_kernel(const float* __restrict__
 __global__ __launch_bounds__(256) void ctc_grad_logits_kernel(const float* __restrict__ logits, const float* __restrict__ lse,
                                                               const float* __restrict__ lpg, const float* __restrict__ alpha,
                                                               const float* __restrict__ beta, const float* __restrict__ nll,
+                                                              const double* __restrict__ offs,
                                                               const int* __restrict__ targets, const int* __restrict__ in_len,
                                                               const int* __restrict__ tg_len, const float* __restrict__ grad_out,
                                                               bf16* __restrict__ dlogits, float* __restrict__ slab,
-                                                              long rows, int N, int C, int Smax, int Lmax, int blank, int rows_per_block) {
+                                                              long rows, int B, int N, int C, int Smax, int Lmax, int blank, int rows_per_block) {
     extern __shared__ float occ[];                      // [C]
     __shared__ float ssum;
     constexpr int MAXIT = 8;                            // C <= 8192
@@ -264,8 +297,9 @@ __global__ __launch_bounds__(256) void ctc_grad_logits_kernel(const float* __res
         // instruction).  The stride (256) is even, so a thread sees either blanks only or labels only: blanks are summed in
         // registers, then per wave (no barrier), and added with one atomic per wave - as is S, the sum of all occupancies.
         float tot = 0.f, blk = 0.f;
+        const float adj = (float)(offs[bt] + offs[(long)B * N + bt] + offs[2L * B * N + b]);      // see ctc_grad_kernel
         for (int s = threadIdx.x; s < L; s += 256) {
-            const float o = __expf(alpha[base + s] + beta[base + s] + nl - lpg[base + s]);
+            const float o = __expf(alpha[base + s] + beta[base + s] - lpg[base + s] + adj);
             if (s & 1) atomicAdd(&occ[targets[(long)b * Smax + (s >> 1)]], o); else blk += o;
             tot += o;
         }
@@ -298,15 +332,17 @@ __global__ __launch_bounds__(256) void ctc_grad_logits_kernel(const float* __res
 
 SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, hipStream_t stream);
 
-// Workspace contract: lpg, alpha, beta are f32 [B][N][Lmax] with Lmax = 2*Smax+1 (caller-allocated).
+// Workspace contract: lpg, alpha, beta are f32 [B][N][Lmax] with Lmax = 2*Smax+1 (caller-allocated); offs is f64 [2*B*N + B]:
+// the per-frame offsets of the renormalised alpha rows, of the beta rows, and the nll in f64 (read back by the backward).
 // targets int32 [B][Smax]; input_lengths / target_lengths int32 [B].  nll f32 [B] (loss = sum).
 static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, float* lse, const int32_t* targets, const int32_t* input_lengths,
-                        const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
+                        const int32_t* target_lengths, float* lpg, float* alpha, float* beta, double* offs, float* nll,
                         int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
     if (B == 0) return 0;
+    SCONF_REQUIRE(offs != nullptr, "%s: the f64 offset workspace (2*B*N + B doubles) is required", who);
     const int Lmax = (int)(2 * Smax + 1);
     SCONF_REQUIRE(blank >= 0 && blank < C, "%s: blank %d out of range", who, blank);
-    SCONF_REQUIRE((long)(Lmax + 2) * 8 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);
+    SCONF_REQUIRE((long)(Lmax + 2) * 8 + 128 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);
     SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "%s: C must be a multiple of 4 and one row must fit LDS (%ld classes)", who, (long)C);
     const dim3 gg((unsigned)std::min<long>(B * N, 65536));
     if (from_logits) hipLaunchKernelGGL(ctc_gather_kernel<true>, gg, dim3(256), (size_t)C * 4, stream, in, targets, input_lengths, target_lengths,
@@ -316,21 +352,21 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
-    const size_t sh = (size_t)2 * (Lmax + 2) * sizeof(float);
+    const size_t sh = ((size_t)2 * (Lmax + 2) + 32) * sizeof(float);
     SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
 #define L(MS) do { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
         hipLaunchKernelGGL((ctc_alphabeta_kernel<MS>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
-                           target_lengths, alpha, beta, nll, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
+                           target_lengths, alpha, beta, nll, offs, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
     if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
 #undef L
     return 0;
 }
 
 SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, const int32_t* input_lengths,
-                            const int32_t* target_lengths, float* lpg, float* alpha, float* beta, float* nll,
+                            const int32_t* target_lengths, float* lpg, float* alpha, float* beta, double* offs, float* nll,
                             int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
-    if (ctc_fwd_impl("sconf_ctc_fwd", false, log_probs, nullptr, targets, input_lengths, target_lengths, lpg, alpha, beta, nll, B, N, C, Smax, blank, stream)) return 1;
+    if (ctc_fwd_impl("sconf_ctc_fwd", false, log_probs, nullptr, targets, input_lengths, target_lengths, lpg, alpha, beta, offs, nll, B, N, C, Smax, blank, stream)) return 1;
     SCONF_LAUNCH_OK("sconf_ctc_fwd");
     return 0;
 }
@@ -339,9 +375,9 @@ SCONF_API int sconf_ctc_fwd(const float* log_probs, const int32_t* targets, cons
 // (B,N) f32, kept for the backward), so neither the log-probabilities nor their gradient exist as (B,N,C) tensors:
 // decoder.py:25 F.log_softmax + exp/train.py:104,249 CTCLoss as one operator.
 SCONF_API int sconf_ctc_fwd_logits(const float* logits, const int32_t* targets, const int32_t* input_lengths,
-                                   const int32_t* target_lengths, float* lse, float* lpg, float* alpha, float* beta, float* nll,
+                                   const int32_t* target_lengths, float* lse, float* lpg, float* alpha, float* beta, double* offs, float* nll,
                                    int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
-    if (ctc_fwd_impl("sconf_ctc_fwd_logits", true, logits, lse, targets, input_lengths, target_lengths, lpg, alpha, beta, nll, B, N, C, Smax, blank, stream)) return 1;
+    if (ctc_fwd_impl("sconf_ctc_fwd_logits", true, logits, lse, targets, input_lengths, target_lengths, lpg, alpha, beta, offs, nll, B, N, C, Smax, blank, stream)) return 1;
     SCONF_LAUNCH_OK("sconf_ctc_fwd_logits");
     return 0;
 }
@@ -352,7 +388,7 @@ SCONF_API int64_t sconf_ctc_bwd_logits_workspace(int64_t rows, int64_t C) { retu
 // colsum_out (optional, f32 [C], ACCUMULATED): column sums of dlogits - the decoder bias gradient; needs the workspace
 // (sconf_ctc_bwd_logits_workspace(B * N, C) floats).
 SCONF_API int sconf_ctc_bwd_logits(const float* logits, const float* lse, const float* lpg, const float* alpha, const float* beta,
-                                   const float* nll, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
+                                   const double* offs, const float* nll, const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
                                    const float* grad_out, void* dlogits_bf16, float* colsum_out, float* workspace,
                                    int64_t B, int64_t N, int64_t C, int64_t Smax, int blank, hipStream_t stream) {
     if (B * N == 0) return 0;
@@ -362,8 +398,8 @@ SCONF_API int sconf_ctc_bwd_logits(const float* logits, const float* lse, const 
     const long rows = B * N;
     const int rpb = colsum_out ? (int)cdiv(rows, CTC_BWD_SLABS) : 1;
     const unsigned grid = (unsigned)cdiv(rows, rpb);
-    hipLaunchKernelGGL(ctc_grad_logits_kernel, dim3(grid), dim3(256), (size_t)C * 4, stream, logits, lse, lpg, alpha, beta, nll, targets,
-                       input_lengths, target_lengths, grad_out, (bf16*)dlogits_bf16, colsum_out ? workspace : nullptr, rows, (int)N, (int)C,
+    hipLaunchKernelGGL(ctc_grad_logits_kernel, dim3(grid), dim3(256), (size_t)C * 4, stream, logits, lse, lpg, alpha, beta, nll, offs, targets,
+                       input_lengths, target_lengths, grad_out, (bf16*)dlogits_bf16, colsum_out ? workspace : nullptr, rows, (int)B, (int)N, (int)C,
                        (int)Smax, Lmax, blank, rpb);
     SCONF_LAUNCH_OK("sconf_ctc_bwd_logits");
     if (colsum_out) return sconf_colsum(workspace, SCONF_F32, colsum_out, (int64_t)grid, C, C, 1.f, stream);     // += over the slabs
@@ -372,7 +408,7 @@ SCONF_API int sconf_ctc_bwd_logits(const float* logits, const float* lse, const 
 
 // grad (B,N,C) f32 = grad_out[b] * (exp(lp) - occupancy), zero for t >= input_length (ATen ctc_loss backward).
 // grad_out: f32 [B] (per-sample upstream gradient of the nll vector) or null (= 1).
-SCONF_API int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const float* nll,
+SCONF_API int sconf_ctc_bwd(const float* log_probs, const float* lpg, const float* alpha, const float* beta, const double* offs, const float* nll,
                             const int32_t* targets, const int32_t* input_lengths, const int32_t* target_lengths,
                             const float* grad_out, float* grad, int64_t B, int64_t N, int64_t C, int64_t Smax, int blank,
                             hipStream_t stream) {
@@ -380,8 +416,8 @@ SCONF_API int sconf_ctc_bwd(const float* log_probs, const float* lpg, const floa
     SCONF_REQUIRE(C % 4 == 0, "sconf_ctc_bwd: C must be a multiple of 4");
     SCONF_REQUIRE(C * 4 <= 64 * 1024, "sconf_ctc_bwd: %ld classes do not fit LDS", (long)C);
     const int Lmax = (int)(2 * Smax + 1);
-    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)(B * N)), dim3(256), (size_t)C * 4, stream, log_probs, lpg, alpha, beta, nll,
-                       targets, input_lengths, target_lengths, grad_out, grad, (int)N, (int)C, (int)Smax, Lmax, blank);
+    hipLaunchKernelGGL(ctc_grad_kernel, dim3((unsigned)(B * N)), dim3(256), (size_t)C * 4, stream, log_probs, lpg, alpha, beta, nll, offs,
+                       targets, input_lengths, target_lengths, grad_out, grad, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank);
     SCONF_LAUNCH_OK("sconf_ctc_bwd");
     return 0;
 }

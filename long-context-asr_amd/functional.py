@@ -657,7 +657,7 @@ class HeadCTCFn(Function):
         pnw, pnb, pwf, pbf = ctx.P
         sv = ctx.saved_tensors
         nw, nb, wft, bff, hn, logits, nll, targets, input_lengths, target_lengths = sv[:10]
-        ws = tuple(sv[10:10 + nws]) if nws else (None, None, None, None)
+        ws = tuple(sv[10:10 + nws]) if nws else (None,) * 5
         sn = sv[10 + nws:]
         gbf = _G(pbf)
         dl = ops.ctc_bwd_logits(logits.view(B, -1, logits.shape[-1]), ws, nll, targets, input_lengths, target_lengths,
@@ -756,7 +756,7 @@ class CTCFn(Function):
     def backward(ctx, dnll):
         sv = ctx.saved_tensors
         lp, nll, targets, input_lengths, target_lengths = sv[:5]
-        ws = tuple(sv[5:]) if len(sv) > 5 else (None, None, None)
+        ws = tuple(sv[5:]) if len(sv) > 5 else (None,) * 4
         g = ops.ctc_bwd(lp, ws, nll, targets, input_lengths, target_lengths, dnll.contiguous().to(F32), ctx.blank)
         return g, None, None, None, None
 

@@ -45,10 +45,10 @@ PROTOTYPES = {
     'sconf_sub_stage01_fwd': [vp, i32, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_stage01_bwd': [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_sub_silu_transpose': [i32, vp, vp, vp, i64, i64, i64, vp],
-    'sconf_ctc_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
-    'sconf_ctc_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
-    'sconf_ctc_fwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
-    'sconf_ctc_bwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_fwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_bwd': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_fwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
+    'sconf_ctc_bwd_logits': [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i32, vp],
     'sconf_overlap_add_exp': [vp, i64, i64, i64, i64, i64, vp, vp, i64, vp],
     'sconf_overlap_finalize': [vp, vp, vp, i64, i64, vp],
     'sconf_argmax_rows': [vp, i64, i64, vp, vp],

@@ -504,14 +504,15 @@ def ctc_fwd(log_probs: torch.Tensor, targets: torch.Tensor, input_lengths: torch
     alpha = torch.empty(B, N, L, dtype=torch.float32, device=dev)
     beta = torch.empty(B, N, L, dtype=torch.float32, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
+    offs = torch.empty(2 * B * N + B, dtype=torch.float64, device=dev)          # per-frame offsets of the renormalised rows + nll in f64
     _lib.call('sconf_ctc_fwd', _p(log_probs), _p(targets), _p(input_lengths), _p(target_lengths), _p(lpg), _p(alpha), _p(beta),
-              _p(nll), B, N, Cn, Smax, int(blank), _stream())
-    return nll, (lpg, alpha, beta)
+              _p(offs), _p(nll), B, N, Cn, Smax, int(blank), _stream())
+    return nll, (lpg, alpha, beta, offs)
 
 
 def ctc_fwd_logits(logits: torch.Tensor, targets: torch.Tensor, input_lengths: torch.Tensor, target_lengths: torch.Tensor, blank: int):
     """CTC loss straight from the decoder's logits (B,N,C) f32 (log_softmax folded into the emission gather).
-    Returns nll (B,) f32 and the workspace (lse (B,N), lpg, alpha, beta) the backward needs."""
+    Returns nll (B,) f32 and the workspace (lse (B,N), lpg, alpha, beta, offs) the backward needs."""
     _chk(logits, 'logits', torch.float32); _chk(targets, 'targets', torch.int32)
     _chk(input_lengths, 'input_lengths', torch.int32); _chk(target_lengths, 'target_lengths', torch.int32)
     B, N, Cn = logits.shape
@@ -523,16 +524,17 @@ def ctc_fwd_logits(logits: torch.Tensor, targets: torch.Tensor, input_lengths: t
     alpha = torch.empty(B, N, L, dtype=torch.float32, device=dev)
     beta = torch.empty(B, N, L, dtype=torch.float32, device=dev)
     nll = torch.empty(B, dtype=torch.float32, device=dev)
+    offs = torch.empty(2 * B * N + B, dtype=torch.float64, device=dev)
     _lib.call('sconf_ctc_fwd_logits', _p(logits), _p(targets), _p(input_lengths), _p(target_lengths), _p(lse), _p(lpg), _p(alpha),
-              _p(beta), _p(nll), B, N, Cn, Smax, int(blank), _stream())
-    return nll, (lse, lpg, alpha, beta)
+              _p(beta), _p(offs), _p(nll), B, N, Cn, Smax, int(blank), _stream())
+    return nll, (lse, lpg, alpha, beta, offs)
 
 
 def ctc_bwd_logits(logits, ws, nll, targets, input_lengths, target_lengths, grad_out: Optional[torch.Tensor], blank: int,
                    colsum_into: Optional[torch.Tensor] = None) -> torch.Tensor:
     """d nll / d logits (B,N,C) in bf16 (CTC gradient through log_softmax), scaled by grad_out (B,) f32 if given;
     colsum_into (f32, C elements): += its column sums (the decoder bias gradient), same pass."""
-    lse, lpg, alpha, beta = ws
+    lse, lpg, alpha, beta, offs = ws
     B, N, Cn = logits.shape
     dl = torch.empty(B, N, Cn, dtype=torch.bfloat16, device=logits.device)
     if grad_out is not None: _chk(grad_out, 'grad_out', torch.float32)
@@ -541,17 +543,17 @@ def ctc_bwd_logits(logits, ws, nll, targets, input_lengths, target_lengths, grad
         _chk(colsum_into, 'colsum_into', torch.float32)
         if colsum_into.numel() != Cn: raise ValueError('colsum_into must have one element per class')
         wsp = torch.empty(int(_lib.load().sconf_ctc_bwd_logits_workspace(B * N, Cn)), dtype=torch.float32, device=logits.device)
-    _lib.call('sconf_ctc_bwd_logits', _p(logits), _p(lse), _p(lpg), _p(alpha), _p(beta), _p(nll), _p(targets), _p(input_lengths),
+    _lib.call('sconf_ctc_bwd_logits', _p(logits), _p(lse), _p(lpg), _p(alpha), _p(beta), _p(offs), _p(nll), _p(targets), _p(input_lengths),
               _p(target_lengths), _p(grad_out), _p(dl), _p(colsum_into), _p(wsp), B, N, Cn, targets.shape[1], int(blank), _stream())
     return dl
 
 
 def ctc_bwd(log_probs, ws, nll, targets, input_lengths, target_lengths, grad_out: Optional[torch.Tensor], blank: int) -> torch.Tensor:
-    lpg, alpha, beta = ws
+    lpg, alpha, beta, offs = ws
     B, N, Cn = log_probs.shape
     grad = torch.empty_like(log_probs)
     if grad_out is not None: _chk(grad_out, 'grad_out', torch.float32)
-    _lib.call('sconf_ctc_bwd', _p(log_probs), _p(lpg), _p(alpha), _p(beta), _p(nll), _p(targets), _p(input_lengths),
+    _lib.call('sconf_ctc_bwd', _p(log_probs), _p(lpg), _p(alpha), _p(beta), _p(offs), _p(nll), _p(targets), _p(input_lengths),
               _p(target_lengths), _p(grad_out), _p(grad), B, N, Cn, targets.shape[1], int(blank), _stream())
     return grad
 

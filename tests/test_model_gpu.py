@@ -326,9 +326,9 @@ def test_full_size_properties_c3_shape():
     loss.backward()
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and float(loss) > 0
-    # CTC grad rows sum to ~0.  f32 log-space alpha/beta reach |-8.3 * 2048| ~ 1.7e4 where one f32 ulp is
-    # 2e-3, so the per-row total posterior drifts by a few 1e-2 over 2048 steps (torch's f32 CTC has the same limit).
-    assert float(lp.grad.sum(-1).abs().max()) < 6e-2
+    # CTC grad rows sum to ~0.  Round 2 allowed 6e-2 here (plain f32 log-space rows drift with |alpha| ~ 8 N, as
+    # torch's f32 op does); the lattice rows are renormalised per frame now (csrc/ctc.hip) and the sums are exact to 1e-3.
+    assert float(lp.grad.sum(-1).abs().max()) < 1e-3
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
 
 
@@ -478,10 +478,11 @@ def test_full_size_properties_c5_shape():
     loss.backward()
     torch.cuda.synchronize()
     assert np.isfinite(float(loss)) and float(loss) > 0
-    # CTC gradient rows sum to ~0; f32 log-space alpha/beta reach |-8.3 * 16384| ~ 1.4e5 where one f32 ulp is 1.6e-2, so the
-    # per-row total posterior drifts with the lattice length (the same limit torch's f32 CTC has)
-    # (observed 0.36-0.50 over builds whose logits differ in the last bf16 bit: the bound is on the order of magnitude)
-    assert float(lp.grad.sum(-1).abs().max()) < 0.75
+    # CTC gradient rows sum to ~0.  Round 2 observed 0.36-0.50 here and allowed 0.75: plain f32 log-space alpha/beta reach
+    # |-8.3 * 16384| ~ 1.4e5, where one f32 ulp is 1.6e-2 (torch's f32 CTC has the same limit).  With the lattice rows
+    # renormalised per frame and the offsets in f64 the sums are exact to 1e-3 at this length too (value-level parity against the
+    # f64 oracle: tests/test_kernels_gpu.py::test_ctc_at_the_131072_frame_context_against_the_f64_oracle).
+    assert float(lp.grad.sum(-1).abs().max()) < 1e-3
     assert all(torch.isfinite(p.grad).all() for p in m.parameters())
     # the forward is deterministic: same input, same weights -> same bits (eval of determinism at the 131072-frame size)
     with torch.no_grad():

@@ -85,6 +85,25 @@ def test_numpy_ctc_matches_torch_ctc():
     assert np.allclose(grad, lp.grad.numpy(), atol=2e-5)
 
 
+def test_vectorised_ctc_oracle_matches_the_loop_version_and_torch_f64():
+    """oracle/ctc_ref.py::ctc_loss_and_grad_vec (one numpy expression per frame; the checker of the 16384-frame GPU test) against
+    the pinned pure-Python recursion and against torch's own op in float64 (where torch itself is accurate)."""
+    g = torch.Generator().manual_seed(1)
+    N, C, S = 300, 24, 70
+    lp = torch.log_softmax(torch.randn(1, N, C, generator=g, dtype=torch.float64) * 2, -1).requires_grad_(True)
+    tg = torch.randint(0, C - 1, (1, S), generator=g); tg[0, 3] = tg[0, 2]; tg[0, 10] = tg[0, 8]
+    for T in (N, N - 41):
+        lp.grad = None
+        nll = torch.nn.functional.ctc_loss(lp.transpose(0, 1), tg, torch.tensor([T]), torch.tensor([S]), blank=C - 1, reduction='none')
+        nll.sum().backward()
+        nv, gv = ctc_ref.ctc_loss_and_grad_vec(lp.detach().numpy()[0], tg.numpy()[0], T, S, C - 1)
+        assert abs(nv - float(nll)) / float(nll) < 1e-12
+        assert float(np.abs(gv - lp.grad.numpy()[0]).max()) < 1e-10
+    _, nlls, gl = ctc_ref.ctc_loss_and_grad(lp.detach().numpy()[:, :60], tg.numpy()[:, :12], np.array([60]), np.array([12]), C - 1)
+    nv, gv = ctc_ref.ctc_loss_and_grad_vec(lp.detach().numpy()[0, :60], tg.numpy()[0, :12], 60, 12, C - 1)
+    assert abs(nv - nlls[0]) < 1e-10 and float(np.abs(gv - gl[0]).max()) < 1e-12
+
+
 def test_madgrad_restatement_matches_fixture():
     fx = load_golden('madgrad')
     st = [dict(p=fx[f'p0.{i}'].copy(), gss=np.zeros_like(fx[f'p0.{i}']), s=np.zeros_like(fx[f'p0.{i}']), x0=fx[f'p0.{i}'].copy())
