@@ -8,8 +8,15 @@ all-reduce]) on synthetic mel, BASELINE.json config 3: 6L/768D/6H rotary theta=1
 Prints ONE JSON line (rank 0): metric = spectrogram-frames/sec (whole job), plus
   roofline     : the dominant kernel (NT bf16 MFMA GEMM) timed live with HIP events on its stream over the timed region,
                  algorithmic FLOPs = 2*M*N*K per launch, peak = 2.5 PFLOP/s dense bf16;
+                 roofline.attention = the attention forward / backward launches of the same timed region against the same peak
+                 (algorithmic 4 N^2 H D per sample forward, 10 N^2 H D backward), roofline.hbm = an HBM-bound kernel of the same
+                 region (the pre-norm forward, f32 rows in / bf16 rows out) in GB/s against the 8 TB/s peak;
   cpu_baseline : the CPU oracle (oracle/sconformer_ref.py, fp32, all host cores) on a bounded sample of the same
-                 workload (N=1, rank 0 only).
+                 workload (N=1, rank 0 only); cpu_baseline_t1024: the same for the 1024-frame context;
+  sweep        : (N=1, after the timed region of the headline) the other north-star contexts through the same code, each at its
+                 configured batch: c2 (T=1024), c4 (9L, T=16384, per-layer checkpointing), c5 (3L/2048D, T=131072);
+  dist         : (N>1) backend, gradient bytes all-reduced per step and rank, and how long the step's stream waited for the
+                 all-reduces it could not hide behind the backward.
 """
 import argparse
 import json
@@ -55,6 +62,7 @@ CONFIGS = {
                T=131072, batch=8, name='3L/2048D/16H SConformerXL, seq=131072'),
 }
 PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 MFMA
+PEAK_HBM = 8.0e12               # MI355X_MICROARCH.md: 8.0 TB/s HBM3E (spec; 6.3 TB/s is what a copy reaches)
 
 
 GEMM_KERNELS = {0: 'gemm_kernel<NT> (128x128 tile)', 1: 'gemm256_kernel<false, 2> (NT, 256x256 tile)',
@@ -72,6 +80,7 @@ class GemmTimer:
         self.log = []                                                 # (variant, flops) per timed launch
         self.warm_flops = {}                                          # variant -> flops of one warm-up step
         self.only = None                                              # the variant timed in the timed region
+        self.xpool, self.xused, self.xlog = [], 0, []                 # attention / norm launches
 
     def install(self):
         import lcasr_amd.hip.ops as ops
@@ -106,13 +115,62 @@ class GemmTimer:
             timer.log.append((var, 2.0 * m * n * k, nbytes))
             return out
         ops.gemm = gemm
+        # attention forward / backward and one HBM-bound kernel (the pre-norm forward), timed the same way: ~30 more event
+        # pairs per step
+        inner_af, inner_ab, inner_nf = ops.attn_fwd, ops.attn_bwd, ops.norm_fwd
+
+        def attn_fwd(q, k, v, *a, **kw):
+            if not timer.enabled: return inner_af(q, k, v, *a, **kw)
+            B_, N_, H_, D_ = q.shape
+            return timer._timed('attn_fwd', 4.0 * N_ * N_ * H_ * D_ * B_, 0.0, lambda: inner_af(q, k, v, *a, **kw))
+
+        def attn_bwd(q, k, v, *a, **kw):
+            if not timer.enabled: return inner_ab(q, k, v, *a, **kw)
+            B_, N_, H_, D_ = q.shape
+            return timer._timed('attn_bwd', 10.0 * N_ * N_ * H_ * D_ * B_, 0.0, lambda: inner_ab(q, k, v, *a, **kw))
+
+        def norm_fwd(x, w, b, mode, eps, out_dtype):
+            if not timer.enabled or x.dtype != torch.float32 or out_dtype != torch.bfloat16: return inner_nf(x, w, b, mode, eps, out_dtype)
+            return timer._timed('norm_fwd', 0.0, x.numel() * 6.0, lambda: inner_nf(x, w, b, mode, eps, out_dtype))
+        ops.attn_fwd, ops.attn_bwd, ops.norm_fwd = attn_fwd, attn_bwd, norm_fwd
+
+    def _timed(self, tag, flops, nbytes, fn):
+        if self.xused + 2 > len(self.xpool):
+            return fn()
+        e0, e1 = self.xpool[self.xused], self.xpool[self.xused + 1]
+        self.xused += 2
+        e0.record(); out = fn(); e1.record()
+        self.xlog.append((tag, flops, nbytes))
+        return out
+
+    def extra_summary(self):
+        per = {}
+        for i, (tag, fl, nb) in enumerate(self.xlog):
+            ms = self.xpool[2 * i].elapsed_time(self.xpool[2 * i + 1])
+            d = per.setdefault(tag, [0, 0.0, 0.0, 0.0]); d[0] += 1; d[1] += ms; d[2] += fl; d[3] += nb
+        att, hbm = {}, None
+        for tag, key in (('attn_fwd', 'fwd'), ('attn_bwd', 'bwd')):
+            if tag in per:
+                n, ms, fl, _ = per[tag]
+                att[key] = dict(achieved=round(fl / (ms * 1e-3) / 1e12, 1), unit='TFLOP/s', frac=round(fl / (ms * 1e-3) / PEAK_BF16_DENSE, 4),
+                                launches=n, avg_launch_us=round(ms * 1e3 / n, 1))
+        if att:
+            att['peak'] = PEAK_BF16_DENSE / 1e12
+            att['flops'] = 'algorithmic: forward 4 N^2 H D per sample, backward 10 N^2 H D (dQ + dK/dV kernels together; they execute 14)'
+        if 'norm_fwd' in per:
+            n, ms, _, nb = per['norm_fwd']
+            hbm = dict(bound='hbm', kernel='norm_fwd_kernel (LayerNorm, f32 rows in, bf16 rows out)', achieved=round(nb / (ms * 1e-3) / 1e9, 1),
+                       peak=PEAK_HBM / 1e9, unit='GB/s', frac=round(nb / (ms * 1e-3) / PEAK_HBM, 4), launches=n, avg_launch_us=round(ms * 1e3 / n, 1),
+                       algorithmic_bytes_per_launch=int(nb / n))
+        return att or None, hbm
 
     def prepare(self, n_launches):
         # events only around the dominant kernel's launches: ~100 event records per step instead of ~350, which would
         # themselves cost about 1 ms per step
         self.only = min(self.warm_flops, key=lambda v: (-self.warm_flops[v], v)) if self.warm_flops else None
         self.pool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * n_launches)]
-        for e in self.pool:
+        self.xpool = [torch.cuda.Event(enable_timing=True) for _ in range(2 * 64 * max(1, n_launches // max(self.calls, 1)))]
+        for e in self.pool + self.xpool:
             e.record()                                                # force lazy creation now
         torch.cuda.synchronize()
 
@@ -132,10 +190,11 @@ class GemmTimer:
         # correction, see the file's header); the operand / output bytes of the same launches are computed here
         traffic, src = None, None
         try:
-            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'r02_hbm_traffic.json')))
+            tname = next(n for n in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n)))
+            tj = json.load(open(os.path.join(ROOT, 'profiles', tname)))
             key = GEMM_KERNELS.get(top, '').split(' (')[0]
             if key in tj['kernels']:
-                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], 'profiles/r02_hbm_traffic.json (PMC, same batch)'
+                traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], f'profiles/{tname} (PMC, same batch)'
         except Exception:
             pass
         return dict(bound='mfma', kernel=GEMM_KERNELS.get(top, str(top)), achieved=round(ach / 1e12, 2), peak=PEAK_BF16_DENSE / 1e12,
@@ -157,9 +216,9 @@ def host_cores() -> int:
     return max(1, min(n, int(os.environ.get('SCONF_CPU_THREADS', '16'))))
 
 
-def cpu_baseline(cfg_name: str):
-    """Oracle (CPU fp32 restatement of the reference path) on a bounded sample: B=1 of the same config, one
-    forward+CTC+backward after no warm-up, all host cores."""
+def cpu_baseline(cfg_name: str, budget_s: float = 10.0, parity: bool = True):
+    """Oracle (CPU fp32 restatement of the reference path) on a bounded sample: B=1 of the same config, forward+CTC+backward
+    steps for ~budget_s seconds after one warm-up, all host cores.  parity: also run the HIP path on that very sample."""
     from oracle import sconformer_ref as O
     from lcasr_amd.models.sconformer_xl import SCConformerXL
     cfg = CONFIGS[cfg_name]
@@ -188,10 +247,12 @@ def cpu_baseline(cfg_name: str):
     n = 0
     while True:
         loss = one_step(); n += 1
-        if time.perf_counter() - t0 > 10.0 or n >= 20: break     # bounded: ~10-15 s of CPU work
+        if time.perf_counter() - t0 > budget_s or n >= 20: break # bounded: ~10-15 s of CPU work
     dt = (time.perf_counter() - t0) / n
     res = dict(value=round(T / dt, 1), unit='spectrogram-frames/sec', cores=cores, kind='port',
                sample=f'oracle fp32 forward+CTC+backward, B=1 x T={T}, {n} timed steps after 1 warm-up ({dt:.2f} s/step)', loss=round(loss, 3))
+    if not parity:
+        return res
     # CTC-loss parity at the benchmark size (BASELINE.json metric: "+ CTC-loss parity vs CPU ref"): the HIP path on the very
     # sample the oracle just ran (same seeded weights, same mel, same targets)
     from lcasr_amd.losses import CTCLoss
@@ -211,6 +272,43 @@ def cpu_baseline(cfg_name: str):
     res['hip_loss_two_call_path'] = round(hip_loss2, 3)
     res['ctc_loss_rel_err'] = float(f'{max(abs(hip_loss - loss), abs(hip_loss2 - loss)) / abs(loss):.3e}')
     return res
+
+
+def Fn_clear():
+    """Release everything the previous model held on the device (bf16 weight shadows are keyed on the parameters)."""
+    import gc
+    import lcasr_amd.functional as Fn
+    Fn.clear_weight_cache()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def run_config(name: str, steps: int, warmup: int, batch: int = 0) -> dict:
+    """One BASELINE config through Trainer.step on synthetic data: ms per step and frames / s (single GPU, no event timers)."""
+    from lcasr_amd.models.sconformer_xl import SCConformerXL
+    from lcasr_amd.train import Trainer, synthetic_batch
+    cfg = CONFIGS[name]
+    B, T = batch or cfg['batch'], cfg['T']
+    torch.manual_seed(12345)
+    model = SCConformerXL(**cfg['model']).cuda().train()
+    trainer = Trainer(model, lr=3e-3, clip_value=0.8, global_batch=B)
+    audio, lengths, targets, tl = synthetic_batch(B, T, cfg['model']['vocab_size'], seed=0)
+    loss = None
+    for _ in range(warmup):
+        loss = trainer.step(audio, lengths, targets, tl)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = trainer.step(audio, lengths, targets, tl)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    out = dict(workload=cfg['name'], seq_len=T, per_gpu_batch=B, steps=steps, warmup=warmup, ms_per_step=round(dt * 1e3, 2),
+               frames_per_sec=round(B * T / dt, 1), loss_last_step=round(float(loss), 3),
+               peak_mem_gib=round(torch.cuda.max_memory_allocated() / 2**30, 1))
+    del trainer, model, audio
+    Fn_clear()
+    torch.cuda.reset_peak_memory_stats()
+    return out
 
 
 def spawn_ranks(n: int) -> int:
@@ -238,6 +336,7 @@ def main():
     ap.add_argument('--config', default='c3', choices=list(CONFIGS))
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: config value)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-sweep', action='store_true', help='skip the c2 / c4 / c5 lines after the headline (N=1, c3 only)')
     ap.add_argument('--fwd-only', action='store_true', help='diagnostic (SURVEY 8d "also report fwd-only"): time the training-mode forward alone')
     ap.add_argument('--per-step', action='store_true', help='diagnostic: print per-step GPU times (HIP events, no extra syncs)')
     args = ap.parse_args()
@@ -275,6 +374,7 @@ def main():
     if world > 1:
         broadcast_module_state(model)
     trainer = Trainer(model, lr=3e-3, clip_value=0.8, global_batch=B * world)
+    trainer.sync.profile = world > 1                                          # HIP events around the all-reduce waits (dist.exposed_wait_ms_per_step)
     audio, lengths, targets, tl = synthetic_batch(B, T, cfg['model']['vocab_size'], seed=rank)
 
     timer = GemmTimer()
@@ -322,6 +422,10 @@ def main():
 
     if rank == 0:
         frames = B * T * world * args.steps
+        att, hbm = timer.extra_summary()
+        roof = timer.summary()
+        if roof is not None:
+            roof['attention'], roof['hbm'] = att, hbm
         res = {
             'metric': 'spectrogram-frames/sec (6L/768D, seq=16384)' if args.config == 'c3' else f'spectrogram-frames/sec ({args.config}: {cfg["name"]})',
             'value': round(frames / dt, 1), 'unit': 'spectrogram-frames/sec', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -330,16 +434,35 @@ def main():
             'config': {'workload': cfg['name'] + (', forward only (train mode, no_grad)' if args.fwd_only else ', fwd+CTC+bwd+clip+MADGRAD'), 'per_gpu_batch': B, 'global_batch': B * world, 'seq_len': T,
                        'parallelism': f'dp{world}', 'loss_last_step': round(float(loss), 3)},
             'per_gpu_value': round(frames / dt / world, 1),
-            'roofline': timer.summary(),
+            'roofline': roof,
         }
+        if world > 1:
+            # what an N-GPU deviation from linear is made of: the exchange is one all-reduce(SUM) per 64 MiB slice of the flat f32
+            # gradient buffer, issued from the backward as soon as a slice is final; `exposed_wait_ms_per_step` is how long the
+            # compute stream then still had to wait in GradSync.finish() (HIP events on that stream, this rank)
+            sy = trainer.sync
+            res['dist'] = {'backend': backend + (' (RCCL over xGMI)' if backend == 'nccl' else ''), 'world_size': dist.get_world_size(),
+                           'allreduce_bytes_per_step_per_rank': int(sy.flat_grad.numel() * 4), 'buckets': len(sy.buckets),
+                           'exposed_wait_ms_per_step': sy.exposed_wait_ms(args.steps), 'single_device_rehearsal': bool(os.environ.get('SCONF_SINGLE_DEVICE'))}
         if world == 1 and not args.no_cpu_baseline and args.config == 'c5':
             # the oracle writes attention out as an explicit (H, N, N) f32 matrix: 17 GB per layer at N = 16384, not a bounded sample
             res['cpu_baseline'] = None
         elif world == 1 and not args.no_cpu_baseline:
-            torch.cuda.empty_cache()
+            del trainer, model, audio
+            Fn_clear()
             res['cpu_baseline'] = cpu_baseline(args.config)
             res['ctc_loss_rel_err'] = res['cpu_baseline']['ctc_loss_rel_err']
             res['gpu_over_cpu'] = round(res['value'] / res['cpu_baseline']['value'], 1)
+            if args.config == 'c3':
+                res['cpu_baseline_t1024'] = cpu_baseline('c2', budget_s=4.0, parity=False)
+        if world == 1 and args.config == 'c3' and not args.no_sweep and not args.fwd_only:
+            # the other north-star contexts (1024 and 131072 frames; the 9-layer model) through the same code path, after - and
+            # outside - the timed region of the headline
+            trainer = model = audio = None
+            Fn_clear()
+            res['sweep'] = {name: run_config(name, steps=5, warmup=2) for name in ('c2', 'c4', 'c5')}
+            cb = res.get('cpu_baseline_t1024')
+            if cb: res['sweep']['c2']['gpu_over_cpu'] = round(res['sweep']['c2']['frames_per_sec'] / cb['value'], 1)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

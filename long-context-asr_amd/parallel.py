@@ -67,6 +67,7 @@ class GradSync:
         # backward.  The first backward only counts, per source; from then on a parameter listens to ONE source - the direct
         # one if it ever spoke for it - and is released on that source's last announcement.
         self._seen, self._expect = {'d': {}, 'a': {}}, None
+        self.profile, self._wait_events = False, []           # bench.py: HIP events around the waits in finish()
         if self.world > 1:
             for i, p in enumerate(params):
                 if p.requires_grad:
@@ -129,9 +130,25 @@ class GradSync:
             while self.next_bucket >= 0:                      # whatever the hooks did not release (unused parameters; a rank that
                 self._issue(self.next_bucket)                  # ran no backward in this step contributes its zero gradients)
                 self.next_bucket -= 1
+            ev = None
+            if self.profile and self.flat_grad.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             for h in self.handles:
                 h.wait()
+            if ev is not None:
+                ev[1].record()
+                self._wait_events.append(ev)
         self.reset()
+
+    def exposed_wait_ms(self, last_n: Optional[int] = None) -> Optional[float]:
+        """Mean time (ms) the compute stream spent between entering finish() and the last all-reduce being done, over the last
+        `last_n` steps (profile=True): the part of the exchange the backward did not hide.  None when nothing was recorded."""
+        evs = self._wait_events[-last_n:] if last_n else self._wait_events
+        if not evs:
+            return None
+        torch.cuda.synchronize()
+        return round(sum(a.elapsed_time(b) for a, b in evs) / len(evs), 3)
 
     def remove(self):
         for h in self._hooks:

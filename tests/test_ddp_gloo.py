@@ -245,8 +245,9 @@ def _recording_worker(rank, world, port, out):
         return torch.randint(0, V, (c['audio'].shape[0], int(tl_.max())), generator=g), tl_
 
     losses = tr.train_recording(audio, lens, 256, 64, targets)
-    torch.save(dict(n=len(losses), k=tr.opt.k, data=tr.opt.flat[0].data.clone(), finite=all(bool(torch.isfinite(l)) for l in losses)),
-               out + f'.{rank}')
+    bufs = torch.cat([b.detach().double().reshape(-1) for b in m.buffers()])          # BatchRenorm running statistics + step counters
+    torch.save(dict(n=len(losses), k=tr.opt.k, data=tr.opt.flat[0].data.clone(), finite=all(bool(torch.isfinite(l)) for l in losses), bufs=bufs,
+                    nbt=int(m.layers[0].conv.fn.batch_norm.num_batches_tracked)), out + f'.{rank}')
     dist.destroy_process_group()
 
 
@@ -261,3 +262,6 @@ def test_train_recording_world2_unequal_recordings_stay_in_lockstep(tmp_path):
     assert (r0['n'], r1['n']) == (6, 2) and r0['finite'] and r1['finite']
     assert r0['k'] == r1['k'] == 6
     assert torch.equal(r0['data'], r1['data'])
+    # rank 1 ran 2 forwards, rank 0 six - its BatchRenorm buffers fell behind; rank 0's are re-broadcast at the end of
+    # the recording batch, so the replicas (and whichever rank writes the checkpoint) agree
+    assert r0['nbt'] == 6 and r1['nbt'] == 6 and torch.equal(r0['bufs'], r1['bufs'])

@@ -561,12 +561,12 @@ def test_ctc(ops, B, N, C, S, ragged):
     if ragged:
         il[1] = N - 17; tl[1] = max(1, S // 3); il[-1] = max(2 * S + 1, N // 2)
     nll, ws = ops.ctc_fwd(dev(lp), dev(tg), dev(il), dev(tl), C - 1)
-    nllr, _ = R.ctc_fwd(lp, tg, il, tl, C - 1)
-    assert float(((nll.cpu() - nllr) / nllr).abs().max()) < 1e-4, (nll, nllr)
+    nllr, _ = R.ctc_fwd(lp.double(), tg, il, tl, C - 1)                       # torch's op in FLOAT64: its f32 form drifts with N (5.9e-3 of
+    assert float(((nll.cpu() - nllr) / nllr).abs().max()) < 1e-5, (nll, nllr)   # the gradient's maximum at N = 2100, more than this kernel)
     go = torch.tensor([1.0, 0.5, 2.0][:B])
     grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), dev(go), C - 1)
-    gradr = R.ctc_bwd(lp, None, nllr, tg, il, tl, go, C - 1)
-    close(grad, gradr, name='ctc grad', tol=1e-3)                             # renormalised rows: no drift with N (round 2: 5e-3 at N = 2100)
+    gradr = R.ctc_bwd(lp.double(), None, nllr, tg, il, tl, go.double(), C - 1).float()
+    close(grad, gradr, name='ctc grad', tol=2e-4)                             # renormalised rows: no drift with N (round 2: 2e-3 ... 5e-3 against torch f32)
     if B > 1: assert float(grad[1, int(il[1]):].abs().max() if int(il[1]) < N else 0.0) == 0.0
 
 
