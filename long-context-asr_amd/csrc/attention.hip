@@ -18,7 +18,10 @@
 //    no atomics, bitwise reproducible, at the price of recomputing S and dP once more.
 #include "common.h"
 #include <stdlib.h>
+#include <algorithm>
 #include <type_traits>
+#include <vector>
+#include <stdio.h>
 
 namespace {
 
@@ -37,7 +40,22 @@ struct AttnParams {
     float scale;                      // 1/sqrt(D)
     int xcd_remap;                    // 1: XCD-contiguous workgroup order (decode_block)
     const float *rot_cos, *rot_sin;   // backward: (N, D/2) rotary tables or null - dq, dk are returned as gradients of the UNROTATED q, k
+    unsigned long long* stamps;       // diagnostic builds only (-DSCONF_ATTN_STAMP): per (workgroup, wave) segment cycle sums
 };
+
+// In-kernel time stamps (cdna_hip_programming.md section 7): a DIAGNOSTIC build only (make EXTRA=-DSCONF_ATTN_STAMP); in the product
+// build the macros are empty and no stamp executes.  Segment sums are kept per wave and written once after the loop, to a buffer
+// nothing else reads.
+#ifdef SCONF_ATTN_STAMP
+#define STAMP_DECL(n) unsigned long long st_acc_[n] = {}, st_last_ = 0; { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last_ = t_; }
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); st_acc_[i] += t_ - st_last_; st_last_ = t_; } while (0)
+#define STAMP_OUT(n) do { if (p.stamps && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < (n); ++i_) p.stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + i_] = st_acc_[i_]; } while (0)
+#else
+#define STAMP_DECL(n)
+#define STAMP(i)
+#define STAMP_OUT(n)
+#endif
 
 // Workgroup -> (batch, head, row block) for a 1-D launch of nx * H * B workgroups.  The hardware deals consecutive workgroup ids
 // to the 8 XCDs round-robin, so with the natural order the 8 row blocks of one (b, h) land on 8 different XCDs and every XCD's
@@ -172,6 +190,61 @@ __device__ __forceinline__ void dma_tile(const bf16* base, long sn, int row0, in
         const int gr = min(row0 + row, nrows_valid - 1);
         dma16_asm(base + (long)gr * sn + (pos ^ swz) * 8, wbase + (unsigned)(NTHR * i) * 16u);
     }
+}
+
+// ---- LDS-DMA through a buffer descriptor, a whole tile per asm statement (round 3) -----------------------------------------------
+// In-kernel stamps of the 8-wave forward (DESIGN, round 3) showed the DMA ISSUE of dma_tile above on every wave's critical
+// path: 950 cycles per stage for waves 0-3 and 1950 for waves 4-7 (12-25 % of the kernel) - per 16-byte piece a 64-bit address
+// (row clamp, multiply by the row stride, swizzle) rebuilt on the VALU plus an M0 save / set / restore around it.  Here the
+// per-lane part of the address is ONE loop-invariant 32-bit offset (a piece is NTHR / 16 whole rows further down: the swizzle
+// depends on row & 15 only), the rest is scalar: `buffer_load_dwordx4 voff, srd, soff offen lds` with soff and M0 stepped by
+// s_add.  Rows past the tensor need no clamp: the descriptor's range check returns zeros for them (their keys are masked and
+// their query rows are never stored).  3 scalar instructions + the load per piece, M0 saved and restored once per tile.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+__device__ __forceinline__ srd_t make_srd(const void* base, long nbytes) {
+    const unsigned long a = (unsigned long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(nbytes > 0xffffffffL ? 0xffffffffL : nbytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+// bytes of a (rows, D) bf16 view with row stride sn (elements) that start at its first row
+template <int D> __device__ __forceinline__ long view_bytes(int rows, long sn) { return rows > 0 ? ((long)(rows - 1) * sn + D) * 2 : 0; }
+// this lane's source byte offset inside one pass (NTHR / (D / 8) rows) of a [rows][D] tile: the tile_off swizzle on the source chunk
+template <int D, int NTHR> __device__ __forceinline__ unsigned tile_voff(long sn, int tid) {
+    constexpr int CPR = D / 8;
+    static_assert((NTHR / CPR) % 16 == 0, "a pass must be whole groups of 16 rows (the swizzle period)");
+    const int row = tid / CPR, pos = tid % CPR;
+    const int swz = (D == 128) ? (((row & 3) << 2) | ((row >> 2) & 3)) : ((row >> 2) & 3);
+    return (unsigned)(row * sn * 2 + ((pos ^ swz) << 4));
+}
+// NP pieces of a tile: piece k reads srd base + soff + k * sstep + voff and lands at lds_wave_base + k * LSTEP + lane * 16
+#define SCONF_DMA_FIRST "s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %1 offen lds\n\t"
+#define SCONF_DMA_NEXT  "s_add_u32 m0, m0, %6\n\ts_add_u32 %1, %1, %4\n\tbuffer_load_dwordx4 %2, %3, %1 offen lds\n\t"
+#define SCONF_DMA_LAST  "s_mov_b32 m0, %0"
+template <int NP, int LSTEP> __device__ __forceinline__ void dma_pieces(srd_t srd, unsigned voff, unsigned soff, unsigned sstep, unsigned lds_wave_base) {
+    static_assert(NP == 2 || NP == 4 || NP == 8, "tiles of 2, 4 or 8 pieces per wave");
+    unsigned keep;
+    if constexpr (NP == 8)
+        asm volatile(SCONF_DMA_FIRST SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_LAST
+                     : "=&s"(keep), "+s"(soff) : "v"(voff), "s"(srd), "s"(sstep), "s"(lds_wave_base), "n"(LSTEP) : "memory");
+    else if constexpr (NP == 4)
+        asm volatile(SCONF_DMA_FIRST SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_NEXT SCONF_DMA_LAST
+                     : "=&s"(keep), "+s"(soff) : "v"(voff), "s"(srd), "s"(sstep), "s"(lds_wave_base), "n"(LSTEP) : "memory");
+    else
+        asm volatile(SCONF_DMA_FIRST SCONF_DMA_NEXT SCONF_DMA_LAST
+                     : "=&s"(keep), "+s"(soff) : "v"(voff), "s"(srd), "s"(sstep), "s"(lds_wave_base), "n"(LSTEP) : "memory");
+}
+// A [ROWS][128] tile staged by a 512-thread workgroup = ROWS / 32 passes of 8 wave pieces.  Who issues them: every wave its own
+// piece of each pass, or - LOADERS - waves 0-3 only, each also the piece of wave w + 4 (16 rows further down: same swizzle, the
+// LDS block 4 KiB further on).  Stamps of the 8-wave forward: waves 4-7 lose every arbitration on their SIMD (priority, then age:
+// MI355X_MICROARCH.md 'Two waves per SIMD') and are the critical path, while waves 0-3 sit in the stage barrier for a third of
+// the kernel; an LDS-DMA piece costs its issuing wave 75-180 cycles, so the pieces go to the waves that have the slack.  Which
+// waves are the older ones is an observation, not a contract: a different placement changes speed only.
+template <int ROWS, bool LOADERS> __device__ __forceinline__ void dma_tile128(srd_t srd, unsigned voff, long sn, int row0, unsigned lds_tile, int wave_u) {
+    constexpr int PASSES = ROWS / 32;
+    const unsigned rb = (unsigned)(sn * 2);                                       // bytes per row
+    if constexpr (!LOADERS) dma_pieces<PASSES, 8192>(srd, voff, (unsigned)row0 * rb, 32u * rb, lds_tile + (unsigned)wave_u * 1024u);
+    else if (wave_u < 4) dma_pieces<2 * PASSES, 4096>(srd, voff, (unsigned)row0 * rb, 16u * rb, lds_tile + (unsigned)wave_u * 1024u);
 }
 
 // make a fragment array's loads complete, as far as the compiler can tell, HERE (an empty asm that "rewrites" each register)
@@ -551,6 +624,239 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// Round 3: the 8-wave forward, software-pipelined inside the wave, without a running maximum.
+//
+// In-kernel stamps of the round-2 kernel above (B = 128, N = 2048; cycles per 64-key half-tile, waves 0-3 / waves 4-7):
+//   DMA issue 474 / 990, S chain 742 / 1175, softmax 705 / 921, PV chain 635 / 709, stage barrier 1304 / 66  (sum 3930 for
+//   2048 cycles of MFMA work per SIMD).  Three things, in that order:
+//  (1) an LDS-DMA piece costs the issuing wave 75-180 cycles, and the younger half of the workgroup (waves 4-7 lose every
+//      arbitration on their SIMD) was the critical path while waves 0-3 sat in the barrier: waves 0-3 issue ALL pieces now, through
+//      a buffer descriptor (dma_tile128);
+//  (2) S chain -> softmax -> PV chain were three serial segments per wave, and two waves in near lock-step do not overlap each
+//      other's segments: the softmax of the first 32 keys now runs UNDER the S chain of the second 32 and that of the second 32
+//      under the first half of the PV chain - possible because
+//  (3) there is no per-tile maximum any more: the reference point m of the exponentials is the row maximum of the FIRST half-tile
+//      a workgroup sees and never moves (any reference gives the same O / l; bf16 keeps P's relative precision at any magnitude).
+//      Scores that later exceed it simply give P > 1, and f32 l, O have room for 2^100.  Only an overflow (or a row whose
+//      reference was 2^126 above everything it sees later) breaks this: it shows up as a non-finite or zero l at the very end,
+//      and the workgroup then redoes its rows with the careful per-tile maximum (pass 1 below).  No branch in the steady state.
+// ---------------------------------------------------------------------------------------------------------------------------
+// single VALU instructions, opaque to the SLP vectoriser: hipcc packs neighbouring f32 operations into v_pk_*_f32 (then pads dependent
+// ones with s_nop): MI355X_MICROARCH.md - packed f32 beside MFMAs is an anti-lever
+__device__ __forceinline__ float fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
+// l0 += e0 + e2, l1 += e1 + e3 as two independent chains in one statement
+__device__ __forceinline__ void acc4(float& l0, float& l1, float e0, float e1, float e2, float e3) {
+    asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5" : "+v"(l0), "+v"(l1) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+}
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_fwd8p_kernel(const AttnParams p) {
+    constexpr int KT = 128;                            // keys per stage, consumed as two 64-key halves
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TB = KT * 2 * D;                     // bytes of one stage tile
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hh = lane >> 5;
+    const BlkId bid = decode_block(p, (p.N + 255) / 256);
+    const int b = bid.b, h = bid.h, qb0 = bid.x * 256, q0 = qb0 + wave * 32;
+    const int len = p.lengths ? p.lengths[b] : p.N;
+    const bf16* qp = p.q + b * p.q_sb + h * p.q_sh;
+    const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
+    const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
+    const int qi = q0 + (lane & 31);
+    const float c = p.scale * 1.4426950408889634f;
+
+    bf16x8 qf[D / 16];
+    load_bfrags<D>(qf, qp, p.q_sn, q0, p.N, lane);
+    const LaneOffs<D> L(lane);
+
+    const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
+    const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 256 + p.win_right);
+    const int t_lo = kv_lo / KT, t_hi = (kv_hi + KT - 1) / KT;
+    const bool windowed = p.win_left >= 0 || p.win_right >= 0;
+
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const srd_t ksrd = make_srd(kp, view_bytes<D>(p.N, p.k_sn)), vsrd = make_srd(vp, view_bytes<D>(p.N, p.v_sn));
+    const unsigned kvoff = tile_voff<D, 512>(p.k_sn, tid), vvoff = tile_voff<D, 512>(p.v_sn, tid);
+    auto issue = [&](int t, int buf) {                     // K | V stage by LDS-DMA through buffer descriptors, issued by waves 0-3 (dma_tile128)
+        dma_tile128<KT, true>(ksrd, kvoff, p.k_sn, t * KT, lds0 + (unsigned)(buf * 2 * TB), wave_u);
+        dma_tile128<KT, true>(vsrd, vvoff, p.v_sn, t * KT, lds0 + (unsigned)(buf * 2 * TB + TB), wave_u);
+    };
+    // keys this lane's query may see: [key_lo, key_lo + key_rng] (length and window folded into one unsigned range test)
+    const int key_lo = p.win_left >= 0 ? max(0, qi - p.win_left) : 0;
+    const unsigned key_rng = (unsigned)max(-1, (p.win_right >= 0 ? min(len - 1, qi + p.win_right) : len - 1) - key_lo);   // -1 -> none... as unsigned: all
+    const bool none = (p.win_right >= 0 ? min(len - 1, qi + p.win_right) : len - 1) < key_lo;
+    auto mask_block = [&](f32x16& sb, int key0) {          // keys key0 + acc_row(r, hh): -inf outside length / window, branch-free
+        const unsigned t0 = (unsigned)(key0 + 4 * hh - key_lo);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool ok = (t0 + (unsigned)acc_row(r, 0)) <= key_rng && !none;
+            sb[r] = ok ? sb[r] : -INFINITY;
+        }
+    };
+    auto s_chain = [&](const char* sKh, int kt, f32x16& acc) {   // acc = K[32 kt .. +31] Q^T: 8 (fragment read, MFMA) pairs, reads 3 ahead
+        constexpr int NS = D / 16, PF = 3;
+        bf16x8 ka[NS];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int i = 0; i < PF; ++i) ka[i] = frag_row<D>(sKh, L, kt * 32, i);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            if (i + PF < NS) ka[i + PF] = frag_row<D>(sKh, L, kt * 32, i + PF);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[i], qf[i], acc, 0, 0, 0);
+        }
+    };
+
+    f32x16 o[D / 32];
+#pragma unroll
+    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+    float mc = 0.f, l0 = 0.f, l1 = 0.f;                // reference point (scaled, log2 units) and the row sum relative to it (two chains)
+    if (t_lo < t_hi) issue(t_lo, 0);
+    pin_frags(qf);
+    dma_wait_all();
+    __syncthreads();
+    if (t_lo < t_hi) {
+        // the reference: this lane's row maximum over the first half-tile (0 for a row that sees no key there)
+        const int kv0 = t_lo * KT;
+        f32x16 s0, s1;
+        s_chain(smem, 0, s0); s_chain(smem, 1, s1);
+        if (kv0 + 64 > kv_hi || windowed) { mask_block(s0, kv0); mask_block(s1, kv0 + 32); }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mc = (mx > -INFINITY) ? mx * c : 0.f;
+    }
+    const float nmc = -mc;
+    STAMP_DECL(8)
+    // One 64-key half-tile: [S0] [S1 | exp S0] [PV0 | exp S1] [PV1] - the exponentials of one 32-key block run under the MFMAs of
+    // the next group (independent instruction streams in one basic block: hipcc interleaves them).
+    auto exp_block = [&](f32x16& sb, bf16x8& plo, bf16x8& phi) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(fma1(sb[4 * g + j], c, nmc));
+            acc4(l0, l1, e[0], e[1], e[2], e[3]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sb[4 * g + j] = e[j];
+        }
+        plo = pack8(sb, 0); phi = pack8(sb, 1);
+    };
+    auto half_tile = [&](const char* sKh, const char* sVh, int kv0, const bool MASKED) {      // MASKED: wave-uniform
+        f32x16 s0, s1;
+        bf16x8 pf[2][2];
+        s_chain(sKh, 0, s0);
+        if (MASKED) mask_block(s0, kv0);
+        STAMP(1);
+        s_chain(sKh, 1, s1);
+        exp_block(s0, pf[0][0], pf[0][1]);
+        if (MASKED) mask_block(s1, kv0 + 32);
+        STAMP(2);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)              // PV of keys 0..31: d-block i >> 1, k-step i & 1
+            o[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 16 * (i & 1), i >> 1), pf[0][i & 1], o[i >> 1], 0, 0, 0);
+        exp_block(s1, pf[1][0], pf[1][1]);
+        STAMP(3);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)              // PV of keys 32..63
+            o[i >> 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 32 + 16 * (i & 1), i >> 1), pf[1][i & 1], o[i >> 1], 0, 0, 0);
+        STAMP(4);
+    };
+    for (int t = t_lo; t < t_hi; ++t) {
+        const int cur = (t - t_lo) & 1;
+        const char* sK = smem + cur * 2 * TB;
+        const char* sV = sK + TB;
+        if (t + 1 < t_hi) issue(t + 1, cur ^ 1);             // next K/V tile streams into the other buffer during this tile
+        STAMP(0);
+        for (int half = 0; half < KT / 64; ++half) {
+            const int kv0 = t * KT + half * 64;
+            if (kv0 >= kv_hi) break;                       // uniform: the second half of the last stage may be past the keys
+            const char* sKh = sK + half * 64 * 2 * D;
+            const char* sVh = sV + half * 64 * 2 * D;
+            half_tile(sKh, sVh, kv0, kv0 + 64 > kv_hi || windowed);
+        }
+        dma_wait_all();                                      // the next stage has landed (issued a stage of MFMAs ago)
+        __syncthreads();
+        STAMP(5);
+    }
+    STAMP_OUT(6);
+    float l = l0 + l1;
+    float lt = l + __shfl_xor(l, 32, 64);
+    float mfin = mc;
+    if (__syncthreads_or(qi < len && qi < p.N && !(lt > 0.f && lt < 1e37f))) {
+        // ---- rare: an exponential overflowed (or a row's reference sat 2^126 above everything it saw later): redo this workgroup's
+        // rows with the running reference of the round-2 kernel (per-tile maximum, rescale when a row outgrows it by 2^RESCALE_LOG2)
+#pragma unroll
+        for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[i][r] = 0.f;
+        float m = -INFINITY;
+        l = 0.f;
+        if (t_lo < t_hi) issue(t_lo, 0);
+        dma_wait_all();
+        __syncthreads();
+        for (int t = t_lo; t < t_hi; ++t) {
+            const int cur = (t - t_lo) & 1;
+            const char* sK = smem + cur * 2 * TB;
+            const char* sV = sK + TB;
+            if (t + 1 < t_hi) issue(t + 1, cur ^ 1);
+            for (int half = 0; half < KT / 64; ++half) {
+                const int kv0 = t * KT + half * 64;
+                if (kv0 >= kv_hi) break;
+                const char* sKh = sK + half * 64 * 2 * D;
+                const char* sVh = sV + half * 64 * 2 * D;
+                f32x16 s0, s1;
+                s_chain(sKh, 0, s0); s_chain(sKh, 1, s1);
+                if (kv0 + 64 > kv_hi || windowed) { mask_block(s0, kv0); mask_block(s1, kv0 + 32); }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                if (__any((mx - m) * c > RESCALE_LOG2)) {    // wave-uniform; also the first tile of every row (m = -inf)
+                    const float mn = fmaxf(m, mx);
+                    const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m - mn) * c);
+                    l *= alpha;
+                    m = mn;
+#pragma unroll
+                    for (int i = 0; i < D / 32; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) o[i][r] *= alpha;
+                }
+                const float mcc = (m == -INFINITY) ? 0.f : m * c;
+                float rs = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    s0[r] = __builtin_amdgcn_exp2f(s0[r] * c - mcc); s1[r] = __builtin_amdgcn_exp2f(s1[r] * c - mcc);
+                    rs += s0[r] + s1[r];
+                }
+                l += rs;
+                const bf16x8 p00 = pack8(s0, 0), p01 = pack8(s0, 1), p10 = pack8(s1, 0), p11 = pack8(s1, 1);
+#pragma unroll
+                for (int db = 0; db < D / 32; ++db) {
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 0, db), p00, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 16, db), p01, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 32, db), p10, o[db], 0, 0, 0);
+                    o[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sVh, L, 48, db), p11, o[db], 0, 0, 0);
+                }
+            }
+            dma_wait_all();
+            __syncthreads();
+        }
+        lt = l + __shfl_xor(l, 32, 64);
+        mfin = (m == -INFINITY) ? 0.f : m * c;
+    }
+    if (qi < p.N) {
+        const bool live = qi < len && lt > 0.f;
+        const float inv = live ? 1.f / lt : 0.f;
+        store_t<D>(o, p.o + b * p.o_sb + (long)qi * p.o_sn + h * p.o_sh, inv, hh);
+        if (hh == 0 && p.lse) p.lse[((long)b * p.H + h) * p.N + qi] = live ? (mfin + __log2f(lt)) * 0.6931471805599453f : INFINITY;
+    }
+}
+
 // delta[b][h][n] = sum_d dO * O
 template <int D>
 __global__ void attn_delta_kernel(const AttnParams p) {
@@ -746,11 +1052,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
 
     // a stage = Q | dO | lse[64] | delta[64], all by asm-issued LDS-DMA (the statistics as two 4-byte-per-lane pieces): the loop
     // holds no vector-memory operation the compiler knows of, so none of its waits can drain the DMA in flight
+    const srd_t qsrd = make_srd(qp, view_bytes<D>(p.N, p.q_sn)), gsrd = make_srd(gp, view_bytes<D>(p.N, p.do_sn));
     auto issue = [&](int t, int buf) {
-        const int tid_ = opaque(tid);                      // offsets recomputed per stage: kept live across the loop they would be spilled
-        dma_tile<D, QR, 512>(qp, p.q_sn, t * QR, p.N, lds0 + (unsigned)(buf * SB), tid_);
-        dma_tile<D, QR, 512>(gp, p.do_sn, t * QR, p.N, lds0 + (unsigned)(buf * SB + TB), tid_);
+        const int tid_ = opaque(tid);                      // the two per-lane offsets are rebuilt per stage (a dozen VALU operations): kept
+        const unsigned qvoff = tile_voff<D, 512>(p.q_sn, tid_), gvoff = tile_voff<D, 512>(p.do_sn, tid_);   // live across the loop they spill
         const int wave_u = __builtin_amdgcn_readfirstlane(tid_ >> 6);    // scalar: the pointer select below stays in SGPRs
+        dma_tile128<QR, true>(qsrd, qvoff, p.q_sn, t * QR, lds0 + (unsigned)(buf * SB), wave_u);          // issued by waves 0-3 (dma_tile128)
+        dma_tile128<QR, true>(gsrd, gvoff, p.do_sn, t * QR, lds0 + (unsigned)(buf * SB + TB), wave_u);
         if (wave_u < 2) {                                  // wave 0: lse, wave 1: delta; rows past the tensor are clamped and masked below
             const int q = min(t * QR + (tid_ & 63), p.N - 1);
             dma4_asm((wave_u == 0 ? lsep : delp) + q, lds0 + (unsigned)(buf * SB + 2 * TB) + 256u * (unsigned)wave_u);
@@ -946,10 +1254,12 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
         for (int r = 0; r < 16; ++r) dqt[i][r] = 0.f;
 
     const unsigned lds0 = __builtin_amdgcn_readfirstlane(lds_addr(smem));
-    auto issue = [&](int t, int buf) {                     // K | V stage by asm-issued LDS-DMA (see dma16_asm)
-        const int tid_ = opaque(tid);
-        dma_tile<D, KT, 512>(kp, p.k_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB), tid_);
-        dma_tile<D, KT, 512>(vp, p.v_sn, t * KT, p.N, lds0 + (unsigned)(buf * 2 * TB + TB), tid_);
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const srd_t ksrd = make_srd(kp, view_bytes<D>(p.N, p.k_sn)), vsrd = make_srd(vp, view_bytes<D>(p.N, p.v_sn));
+    const unsigned kvoff = tile_voff<D, 512>(p.k_sn, tid), vvoff = tile_voff<D, 512>(p.v_sn, tid);
+    auto issue = [&](int t, int buf) {                     // K | V stage by LDS-DMA through buffer descriptors, issued by waves 0-3 (dma_tile128)
+        dma_tile128<KT, true>(ksrd, kvoff, p.k_sn, t * KT, lds0 + (unsigned)(buf * 2 * TB), wave_u);
+        dma_tile128<KT, true>(vsrd, vvoff, p.v_sn, t * KT, lds0 + (unsigned)(buf * 2 * TB + TB), wave_u);
     };
     if (t_lo < t_hi) issue(t_lo, 0);
     pin_frags(qf); pin_frags(gf);
@@ -1040,11 +1350,43 @@ SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* 
     { const char* ex = getenv("SCONF_ATTN_XCD"); p.xcd_remap = !(ex && ex[0] == '0'); }       // A/B switch, read per call
     set_lds_attrs();
     const char* e8 = getenv("SCONF_ATTN_WIDE");            // "0" keeps the 4-wave kernels (A/B, tests); read per call
-    const bool wide = !(e8 && e8[0] == '0') && N >= 256;
+    // the 8-wave kernels address a (batch, head) slice through a buffer descriptor: 32-bit byte offsets
+    const bool fits32 = (N - 1) * std::max(std::max(k_strides[1], v_strides[1]), q_strides[1]) * 2 + 2 * D < (1L << 32);
+    const bool wide = !(e8 && e8[0] == '0') && N >= 256 && fits32;
     if (D == 128 && wide) {
         static bool attr_set = false;
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_fwd8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
-        hipLaunchKernelGGL((attn_fwd8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)attn_fwd8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256);
+            (void)hipFuncSetAttribute((const void*)attn_fwd8p_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256);
+            attr_set = true;
+        }
+        const char* erc = getenv("SCONF_ATTN_RC");         // "0": the round-2 kernel (running maximum per tile); A/B and tests, read per call
+#ifdef SCONF_ATTN_STAMP
+        const long nwg = cdiv(N, 256) * H * B;
+        static unsigned long long* sbuf = nullptr; static long scap = 0;
+        if (scap < nwg * 64) { if (sbuf) (void)hipFree(sbuf); (void)hipMalloc(&sbuf, nwg * 64 * 8); scap = nwg * 64; }
+        (void)hipMemsetAsync(sbuf, 0, nwg * 64 * 8, stream);
+        p.stamps = sbuf;
+#endif
+        if (erc && erc[0] == '0') hipLaunchKernelGGL((attn_fwd8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
+        else hipLaunchKernelGGL((attn_fwd8p_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
+#ifdef SCONF_ATTN_STAMP
+        if (getenv("SCONF_ATTN_STAMP_PRINT")) {
+            (void)hipStreamSynchronize(stream);
+            std::vector<unsigned long long> hb(nwg * 64);
+            (void)hipMemcpy(hb.data(), sbuf, nwg * 64 * 8, hipMemcpyDeviceToHost);
+            double sums[2][8] = {};
+            for (long w = 0; w < nwg * 8; ++w) for (int i = 0; i < 8; ++i) sums[(w & 7) >= 4][i] += (double)hb[w * 8 + i];
+            const double ntile = (double)nwg * 4 * ((N + 63) / 64);          // (wave, half-tile) pairs per wave group
+            static const char* nm[6] = {"dma-issue", "S0", "S1|exp0", "PV0|exp1", "PV1", "wait+barrier"};
+            for (int g = 0; g < 2; ++g) {
+                double tot = 0; for (int i = 0; i < 6; ++i) tot += sums[g][i];
+                fprintf(stderr, "[attn stamps] waves %d-%d: cycles per half-tile %.0f:", 4 * g, 4 * g + 3, tot / ntile);
+                for (int i = 0; i < 6; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], sums[g][i] / ntile, 100.0 * sums[g][i] / tot);
+                fprintf(stderr, "\n");
+            }
+        }
+#endif
     } else if (D == 128) hipLaunchKernelGGL((attn_fwd_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
     else          hipLaunchKernelGGL((attn_fwd_kernel<32>), grid, block, 4 * 64 * 64, stream, p);
     SCONF_LAUNCH_OK("sconf_attn_fwd");
@@ -1084,7 +1426,10 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
     // dQ first: it computes delta = rowsum(dO * O) from fragments it holds anyway and writes it for the dK/dV kernel
     if (D == 128) {
         const char* eq = getenv("SCONF_ATTN_WIDE");
-        if (!(eq && eq[0] == '0') && N >= 256) {
+        int64_t smax = 0;
+        for (int j = 0; j < 8; ++j) smax = std::max(smax, ss[j][1]);
+        const bool fits32 = (N - 1) * smax * 2 + 2 * D < (1L << 32);      // 8-wave kernels: 32-bit byte offsets inside a (batch, head) slice
+        if (!(eq && eq[0] == '0') && N >= 256 && fits32) {
             static bool attr_set = false;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
             hipLaunchKernelGGL((attn_bwd_dq8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
@@ -1092,7 +1437,7 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
             hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
         const char* e8 = getenv("SCONF_ATTN_DKDV8");           // "0" keeps the 4-wave dK/dV kernel (A/B, tests); read per call
         const bool wide = !(e8 && e8[0] == '0');
-        if (wide && N >= 256) {
+        if (wide && N >= 256 && fits32) {
             static bool attr_set = false;
             const int sh8 = 2 * (2 * 64 * 256 + 512) + 256 * 256;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, sh8); attr_set = true; }

@@ -7,14 +7,20 @@
 //   2. alpha/beta  one workgroup per (sample, direction): 2B workgroups run concurrently; the lattice row lives
 //                  in LDS (double-buffered, one barrier per step); lpg rows are prefetched 4 steps ahead into
 //                  registers so the serial chain never waits on HBM.  beta is alpha on the mirrored lattice.
-//                  The rows are stored RENORMALISED (round 3): row t holds alpha_t - A_t, where A_t (f64, one scalar per frame,
-//                  `offs`) accumulates the maximum of every previous stored row.  Plain log-space f32 rows reach |alpha| ~ 1e5 at
-//                  16384 frames (the 131072-frame context): one ulp is 0.008 there and the roundings of the serial chain
-//                  random-walk to a 0.4-0.5 drift of the per-frame gradient sums and a 0.24 relative L2 error of the gradient
-//                  against an f64 lattice - torch's own f32 op has exactly that error (measured).  Renormalised rows stay within
-//                  a few tens of the origin (ulp ~1e-6), the large parts cancel in f64 once per frame (A_t + B_t + nll), and the
-//                  row maximum costs no barrier: wave maxima are published in LDS in front of the step's own barrier and applied
-//                  one step late (any offset sequence is exact; it only has to keep the magnitudes small).
+//                  Round 3 - precision at the 131072-frame context.  Plain log-space f32 rows reach |alpha| ~ 1e5 at 16384
+//                  frames: one ulp is 0.008 there and the roundings of the serial chain add up to a 0.4-0.5 drift of the
+//                  per-frame gradient sums and a 0.24 relative L2 error of the gradient against an f64 lattice - torch's own f32
+//                  op has exactly that error (measured).  Subtracting the row maximum is not enough: with weak emissions the
+//                  prefix probabilities peak hundreds of states ahead of the states the posterior lives on, which then sit
+//                  hundreds to thousands below the maximum (measured: 6e-3 gradient error left at 16384 frames).  So the STATE of
+//                  the recursion (the LDS rows) is f64 and only the transcendental part runs in f32:
+//                      new = m + (double) logf(expf(a - m) + expf(b - m) + expf(c - m)) + emission,   m = max(a, b, c) in f64
+//                  - an absolute error of ~1e-7 per step whatever |alpha| is.  What is STORED for the gradient pass stays f32:
+//                  alpha_t - A_t, with A_t (f64, one scalar per frame, `offs`) tracking the maximum of the previous stored row, so
+//                  the stored values are small where it matters and their rounding is a one-time error, not an accumulated one;
+//                  the large parts cancel in f64 once per frame (A_t + B_t + nll).  The row maximum costs no barrier: wave maxima
+//                  are published in LDS in front of the step's own barrier and used one step late.  (Lattices of more than
+//                  10230 states do not fit the LDS in f64 and run the same code with f32 state.)
 //   3. grad     one workgroup per (b,t) row: occupancy scattered into an LDS histogram over classes, then
 //               grad = g * (exp(lp) - occupancy)   [ATen convention; zero for t >= input_length].
 #include "common.h"
@@ -30,6 +36,13 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     if (m == -INFINITY) return -INFINITY;
     const float md = __builtin_amdgcn_fmed3f(a, b, c), mn = fminf(a, fminf(b, c));
     return m + __logf(1.f + __expf(md - m) + __expf(mn - m));
+}
+// The same with f64 state: maximum and differences in f64, exponentials and logarithm in f32 (arguments <= 0, result in [0, log 3]:
+// ~1e-7 absolute whatever the magnitude of a, b, c).  The term of the maximum is exp(0) = 1 exactly.
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    const double m = fmax(a, fmax(b, c));
+    if (m == -INFINITY) return -INFINITY;
+    return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m)));
 }
 
 // One workgroup per (sample, frame): the frame's whole log-prob row is streamed into LDS with 16-byte loads and the 2S+1 lattice
@@ -83,14 +96,16 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict
     }
 }
 
-// One workgroup per (sample, direction).  MAXS = max lattice states per thread.
-template <int MAXS>
+// One workgroup per (sample, direction).  MAXS = max lattice states per thread; LT = type of the recursion's state (double; float
+// only for lattices that do not fit the LDS in f64).
+template <int MAXS, typename LT>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ targets,
                                                              const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                              float* __restrict__ alpha, float* __restrict__ beta,
                                                              float* __restrict__ nll, double* __restrict__ offs,
                                                              int B, int N, int C, int Smax, int Lmax, int blank) {
-    extern __shared__ float lat[];                      // [2][Lmax + 2], two leading -inf guard cells per row; then [2][16] wave maxima
+    extern __shared__ double lat_raw[];                 // LT [2][Lmax + 2], two leading -inf guard cells per row; then float [2][16] wave maxima
+    LT* lat = reinterpret_cast<LT*>(lat_raw);
     const int b = blockIdx.x % B;
     const bool is_beta = blockIdx.x >= B;
     const int T = in_len[b], S = tg_len[b], L = 2 * S + 1;
@@ -100,7 +115,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     const float* lg = lpg + (long)b * N * Lmax;
     const int nt = blockDim.x, tid = threadIdx.x;
     const int W = Lmax + 2;
-    float* wm = lat + 2 * W;                            // [2][16] per-wave maxima of the row just written
+    float* wm = reinterpret_cast<float*>(lat + 2 * W);  // [2][16] per-wave maxima of the (stored, relative) row just written
     const int nw = nt >> 6, wave = tid >> 6;
     if (T <= 0) { if (!is_beta && tid == 0) { nll[b] = INFINITY; nll64[b] = INFINITY; } return; }
     // Inputs torch.nn.CTCLoss rejects on the host (input_length > N, target_length > Smax, a label outside [0, C)): the lengths
@@ -126,7 +141,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             }
         }
     }
-    for (int i = tid; i < 2 * W; i += nt) lat[i] = -INFINITY;
+    for (int i = tid; i < 2 * W; i += nt) lat[i] = (LT)-INFINITY;
     __syncthreads();
 
     float pf[4][MAXS], nx[4][MAXS];
@@ -144,7 +159,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
         }
     };
     load_group(pf, 0);
-    double A = 0.0;                                      // sum of the offsets subtracted so far (kept by thread 0)
+    double A = 0.0;                                      // offset of the stored row: the sum of the maxima of the previous stored rows
     for (int i0 = 0; i0 < T; i0 += 4) {
         load_group(nx, i0 + 4);                          // prefetch the next 4 time steps
 #pragma unroll
@@ -152,28 +167,28 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             const int i = i0 + j;
             if (i < T) {                                  // uniform across the workgroup
                 const int t = is_beta ? T - 1 - i : i;
-                float* cur = lat + (i & 1) * W + 2;
-                const float* prev = lat + ((i & 1) ^ 1) * W + 2;
-                // this step's offset: the maximum of the previous STORED row (its wave maxima were published before the barrier)
-                float c = 0.f;
+                LT* cur = lat + (i & 1) * W + 2;
+                const LT* prev = lat + ((i & 1) ^ 1) * W + 2;
+                // this step's offset moves by the maximum of the previous STORED row (its wave maxima were published before the barrier)
                 if (i > 0) {
                     const float* pm = wm + ((i & 1) ^ 1) * 16;
                     float m = pm[0];
                     for (int w = 1; w < nw; ++w) m = fmaxf(m, pm[w]);
-                    c = (m == -INFINITY) ? 0.f : m;
+                    if (m != -INFINITY) A += (double)m;
                 }
-                if (tid == 0) { A += (double)c; off_out[t] = A; }
+                if (tid == 0) off_out[t] = A;
                 float mine = -INFINITY;
 #pragma unroll
                 for (int k = 0; k < MAXS; ++k) {
                     const int sp = tid + k * nt;
                     if (sp < L) {
-                        float v;
-                        if (i == 0) v = (sp < 2) ? pf[j][k] : -INFINITY;
-                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : -INFINITY) + (pf[j][k] - c);
+                        LT v;
+                        if (i == 0) v = (sp < 2) ? (LT)pf[j][k] : (LT)-INFINITY;
+                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : (LT)-INFINITY) + (LT)pf[j][k];
                         cur[sp] = v;
-                        out[(long)t * Lmax + (is_beta ? L - 1 - sp : sp)] = v;
-                        mine = fmaxf(mine, v);
+                        const float st = (float)((double)v - A);                 // what the gradient pass reads: relative to the frame's offset
+                        out[(long)t * Lmax + (is_beta ? L - 1 - sp : sp)] = st;
+                        mine = fmaxf(mine, st);
                     }
                 }
                 mine = wave_max(mine);
@@ -187,8 +202,8 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             for (int k = 0; k < MAXS; ++k) pf[j][k] = nx[j][k];
     }
     if (!is_beta && tid == 0) {
-        const float* last = lat + ((T - 1) & 1) * W + 2;
-        const double v = -(A + (double)lse3(last[L - 1], L > 1 ? last[L - 2] : -INFINITY, -INFINITY));
+        const LT* last = lat + ((T - 1) & 1) * W + 2;
+        const double v = -(double)lse3(last[L - 1], L > 1 ? last[L - 2] : (LT)-INFINITY, (LT)-INFINITY);
         nll64[b] = v;
         nll[b] = (float)v;
     }
@@ -342,7 +357,7 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     SCONF_REQUIRE(offs != nullptr, "%s: the f64 offset workspace (2*B*N + B doubles) is required", who);
     const int Lmax = (int)(2 * Smax + 1);
     SCONF_REQUIRE(blank >= 0 && blank < C, "%s: blank %d out of range", who, blank);
-    SCONF_REQUIRE((long)(Lmax + 2) * 8 + 128 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);
+    SCONF_REQUIRE((long)(Lmax + 2) * 8 + 128 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);   // (f32 state)
     SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "%s: C must be a multiple of 4 and one row must fit LDS (%ld classes)", who, (long)C);
     const dim3 gg((unsigned)std::min<long>(B * N, 65536));
     if (from_logits) hipLaunchKernelGGL(ctc_gather_kernel<true>, gg, dim3(256), (size_t)C * 4, stream, in, targets, input_lengths, target_lengths,
@@ -352,13 +367,16 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
-    const size_t sh = ((size_t)2 * (Lmax + 2) + 32) * sizeof(float);
+    const bool f64_state = ((size_t)2 * (Lmax + 2)) * 8 + 128 <= 160 * 1024;   // else f32 state (lattices of more than 10230 states)
+    const size_t sh = ((size_t)2 * (Lmax + 2)) * (f64_state ? 8 : 4) + 128;
     SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
-#define L(MS) do { \
-        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
-        hipLaunchKernelGGL((ctc_alphabeta_kernel<MS>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
+#define L2(MS, LT) do { \
+        if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
+        hipLaunchKernelGGL((ctc_alphabeta_kernel<MS, LT>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
                            target_lengths, alpha, beta, nll, offs, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
+#define L(MS) do { if (f64_state) L2(MS, double); else L2(MS, float); } while (0)
     if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
+#undef L2
 #undef L
     return 0;
 }
