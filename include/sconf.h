@@ -120,7 +120,9 @@ int sconf_mask_rows(void* x, int dtype, const int32_t* lengths, int64_t B, int64
 /* Flash attention, bidirectional, head_dim 32 or 128; replaces FlashSelfAttention.forward(qkv[,key_padding_mask],
  * cu_seqlens, max_seqlen) = flash_attn_qkvpacked_func / flash_attn_varlen_qkvpacked_func (attention.py:200-257,
  * 527-535) and F.scaled_dot_product_attention (attention.py:541).  q,k,v,o: bf16 (B,N,H,D) views with element
- * strides {batch, token, head}; lengths: int32 [B] or NULL; window (-1 = unbounded); lse: f32 (B,H,N). */
+ * strides {batch, token, head}; lengths: int32 [B] or NULL; window (-1 = unbounded); lse: f32 (B,H,N).
+ * sconf_attn_bwd: delta is f32 scratch of 2*B*H*N floats (the dQ kernel, which runs first, leaves the row statistics of the
+ * dK/dV kernel there: -rowsum(dO*O) and -lse*log2(e)). */
 int sconf_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const int32_t* lengths,
                    int64_t B, int64_t N, int64_t H, int64_t D, const int64_t* q_strides /*host*/, const int64_t* k_strides /*host*/,
                    const int64_t* v_strides /*host*/, const int64_t* o_strides /*host*/, int win_left, int win_right,

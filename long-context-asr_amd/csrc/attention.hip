@@ -642,13 +642,34 @@ __global__ __launch_bounds__(512) void attn_fwd8_kernel(const AttnParams p) {
 //      reference was 2^126 above everything it sees later) breaks this: it shows up as a non-finite or zero l at the very end,
 //      and the workgroup then redoes its rows with the careful per-tile maximum (pass 1 below).  No branch in the steady state.
 // ---------------------------------------------------------------------------------------------------------------------------
-// single VALU instructions, opaque to the SLP vectoriser: hipcc packs neighbouring f32 operations into v_pk_*_f32 (then pads dependent
-// ones with s_nop): MI355X_MICROARCH.md - packed f32 beside MFMAs is an anti-lever
-__device__ __forceinline__ float fma1(float a, float b, float c) { float r; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; }
-// l0 += e0 + e2, l1 += e1 + e3 as two independent chains in one statement
-__device__ __forceinline__ void acc4(float& l0, float& l1, float e0, float e1, float e2, float e3) {
-    asm("v_add_f32 %0, %0, %2\n\tv_add_f32 %1, %1, %3\n\tv_add_f32 %0, %0, %4\n\tv_add_f32 %1, %1, %5" : "+v"(l0), "+v"(l1) : "v"(e0), "v"(e1), "v"(e2), "v"(e3));
+// The softmax arithmetic of four scores as ONE asm statement of single VALU instructions.  Why asm: hipcc's SLP vectoriser packs
+// neighbouring f32 operations into v_pk_mul / v_pk_add and pays two v_mov per pair (and an s_nop behind each dependent packed
+// operation): MI355X_MICROARCH.md - packed f32 beside MFMAs is an anti-lever.  Why four at a time: inside an asm statement
+// nobody pads hazards (cdna_hip_programming.md 5.7 item 2) - a VALU instruction that reads the result of the v_exp_f32 right in
+// front of it gets a stale register (this cost a wrong dK once) - so the four fma, the four exponentials and the four
+// consumers are issued in that order and every result is read four instructions after it was produced.
+//   e[j] = exp2(s[j] * c + m);  l0 += e[0] + e[2];  l1 += e[1] + e[3]                                   (forward)
+__device__ __forceinline__ void exp4_sum(float (&e)[4], float s0, float s1, float s2, float s3, float c, float m, float& l0, float& l1) {
+    asm("v_fma_f32 %0, %6, %10, %11\n\tv_fma_f32 %1, %7, %10, %11\n\tv_fma_f32 %2, %8, %10, %11\n\tv_fma_f32 %3, %9, %10, %11\n\t"
+        "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+        "v_add_f32 %4, %4, %0\n\tv_add_f32 %5, %5, %1\n\tv_add_f32 %4, %4, %2\n\tv_add_f32 %5, %5, %3"
+        : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "+v"(l0), "+v"(l1)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c), "v"(m));
 }
+//   p[j] = exp2(s[j] * c + nl[j]);  d[j] *= p[j]                                                        (backward: dS = P dP')
+__device__ __forceinline__ void exp4_mul(float (&pr)[4], float s0, float s1, float s2, float s3, float c, float n0, float n1, float n2, float n3,
+                                         float& d0, float& d1, float& d2, float& d3) {
+    asm("v_fma_f32 %0, %8, %12, %13\n\tv_fma_f32 %1, %9, %12, %14\n\tv_fma_f32 %2, %10, %12, %15\n\tv_fma_f32 %3, %11, %12, %16\n\t"
+        "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+        "v_mul_f32 %4, %4, %0\n\tv_mul_f32 %5, %5, %1\n\tv_mul_f32 %6, %6, %2\n\tv_mul_f32 %7, %7, %3"
+        : "=&v"(pr[0]), "=&v"(pr[1]), "=&v"(pr[2]), "=&v"(pr[3]), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
+}
+// hipcc pads the wait states between an MFMA and a VALU instruction IT emits that reads the result (18 after a 16-pass MFMA); an asm
+// statement is not such an instruction.  The first asm statement that reads an MFMA result stands behind this guard: it makes
+// the accumulator opaque at this point and spends the wait states.
+__device__ __forceinline__ void mfma_guard(f32x16& a) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a)); }
+__device__ __forceinline__ void mfma_guard(f32x16& a, f32x16& b) { asm volatile("s_nop 15\n\ts_nop 3" : "+v"(a), "+v"(b)); }
 
 template <int D>
 __global__ __launch_bounds__(512) void attn_fwd8p_kernel(const AttnParams p) {
@@ -735,12 +756,11 @@ __global__ __launch_bounds__(512) void attn_fwd8p_kernel(const AttnParams p) {
     // One 64-key half-tile: [S0] [S1 | exp S0] [PV0 | exp S1] [PV1] - the exponentials of one 32-key block run under the MFMAs of
     // the next group (independent instruction streams in one basic block: hipcc interleaves them).
     auto exp_block = [&](f32x16& sb, bf16x8& plo, bf16x8& phi) {
+        mfma_guard(sb);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float e[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) e[j] = __builtin_amdgcn_exp2f(fma1(sb[4 * g + j], c, nmc));
-            acc4(l0, l1, e[0], e[1], e[2], e[3]);
+            exp4_sum(e, sb[4 * g], sb[4 * g + 1], sb[4 * g + 2], sb[4 * g + 3], c, nmc, l0, l1);
 #pragma unroll
             for (int j = 0; j < 4; ++j) sb[4 * g + j] = e[j];
         }
@@ -896,8 +916,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
     const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
     const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
-    const float* lsep = p.lse + ((long)b * p.H + h) * p.N;
-    const float* delp = p.delta + ((long)b * p.H + h) * p.N;
+    const float* delp = p.delta + ((long)b * p.H + h) * p.N;                       // -delta        } written by the dQ kernel,
+    const float* lsep = delp + (long)p.B * p.H * p.N;                                // -lse log2(e)  } which runs first
     const int key = k0 + (lane & 31);
     const float c = p.scale * 1.4426950408889634f;
 
@@ -924,7 +944,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_kernel(const AttnParams 
 
     float st_l = 0.f, st_d = 0.f;
     auto gload_stats = [&](int q0) {
-        if (tid < 32) { const int q = q0 + tid; st_l = (q < len) ? lsep[q] * 1.4426950408889634f : INFINITY; st_d = (q < len) ? delp[q] : 0.f; }
+        if (tid < 32) { const int q = q0 + tid; st_l = (q < len) ? -lsep[q] : INFINITY; st_d = (q < len) ? -delp[q] : 0.f; }
     };
     auto lstore_stats = [&](char* s) {
         if (tid < 32) { reinterpret_cast<float*>(s + 2 * TB)[tid] = st_l; reinterpret_cast<float*>(s + 2 * TB + 128)[tid] = st_d; }
@@ -1026,8 +1046,8 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
     const bf16* kp = p.k + b * p.k_sb + h * p.k_sh;
     const bf16* vp = p.v + b * p.v_sb + h * p.v_sh;
     const bf16* gp = p.dout + b * p.do_sb + h * p.do_sh;
-    const float* lsep = p.lse + ((long)b * p.H + h) * p.N;
-    const float* delp = p.delta + ((long)b * p.H + h) * p.N;
+    const float* delp = p.delta + ((long)b * p.H + h) * p.N;                       // -delta        } written by the dQ kernel,
+    const float* lsep = delp + (long)p.B * p.H * p.N;                                // -lse log2(e)  } which runs first
     const int key = k0 + (lane & 31);
     const float c = p.scale * 1.4426950408889634f;
 
@@ -1039,6 +1059,11 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
     dma_tile<D, 256, 512>(vp, p.v_sn, kb0, p.N, lds0 + (unsigned)(2 * SB), tid);
     const char* sVw = sVt + wave * 32 * 2 * D;
     const bool mask_wg = p.win_left >= 0 || p.win_right >= 0 || kb0 + 256 > len;     // uniform per workgroup
+    // queries that may see this lane's key: [q_first, q_first + q_range]  (key in [q - left, q + right], q < len, key < len)
+    const int q_first = p.win_right >= 0 ? max(0, key - p.win_right) : 0;
+    const int q_last = key < len ? (p.win_left >= 0 ? min(len - 1, key + p.win_left) : len - 1) : -1;
+    const unsigned q_range = q_last >= q_first ? (unsigned)(q_last - q_first) : 0u;
+    const bool q_none = q_last < q_first;
 
     const int q_lo = p.win_right < 0 ? 0 : max(0, kb0 - p.win_right);
     const int q_hi = min(len, p.win_left < 0 ? len : kb0 + 256 + p.win_left);
@@ -1068,6 +1093,7 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
     pin_frags(kf);
     dma_wait_all();
     __syncthreads();
+    STAMP_DECL(8)
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sQ = smem + cur * SB;
@@ -1078,39 +1104,51 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
         const bool need_mask = mask_wg || (t + 1) * QR > len;                         // uniform
         const int x32 = opaque(32);                    // see frag_tr: keeps 4 derived offsets out of the (full) register file
         const int hh = (opaque(tid) >> 5) & 1;         // re-derived per stage for the same reason (shadows the kernel-scope hh)
+        STAMP(0);
 #pragma unroll
         for (int sub = 0; sub < 2; ++sub) {            // two 32-query sub-tiles per stage
             const int rb = 32 * sub, q0 = t * QR + rb;
+            // S = Q K^T from zero; dP' = dO V^T - delta: the chain STARTS from the rows' -delta (16 accumulator rows = 16 queries,
+            // read straight from the stage's statistics in LDS), so dS = P dP' needs no subtraction.  Then per score: one fma
+            // (scale and -lse), one exponential, one multiply - as single VALU instructions (asm helpers): left to itself hipcc
+            // packs pairs into v_pk_mul / v_pk_add and pays two v_mov per pair for it.
             f32x16 s, dp;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+            for (int g = 0; g < 4; ++g) {
+                const float4 d4 = *reinterpret_cast<const float4*>(sD + rb + 8 * g + 4 * hh);
+                dp[4 * g] = d4.x; dp[4 * g + 1] = d4.y; dp[4 * g + 2] = d4.z; dp[4 * g + 3] = d4.w;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s[r] = 0.f;
 #pragma unroll
             for (int st = 0; st < D / 16; ++st) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sQ, L, rb, st), kf[st], s, 0, 0, 0);     // S[q][key]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sG, L, rb, st), frag_row<D>(sVw, L, 0, st), dp, 0, 0, 0);
             }
+            STAMP(1);
+            // Masked scores become -inf BEFORE the exponential (one unsigned range test and a select per score, branch-free): written
+            // as `ok ? exp2(..) : 0` hipcc branched around every single exponential - 16 s_and_saveexec / s_cbranch pairs per
+            // sub-tile, 1700-1950 cycles for ~460 cycles of arithmetic (in-kernel stamps, round 3), in every tile, masked or not.
+            if (need_mask) {                               // uniform
+                const unsigned t0 = (unsigned)(q0 + 4 * hh - q_first);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[r] = (t0 + (unsigned)acc_row(r, 0) <= q_range && !q_none) ? s[r] : -INFINITY;
+            }
+            mfma_guard(s, dp);
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const float4 a = *reinterpret_cast<const float4*>(sL + rb + 8 * g + 4 * hh);
-                const float4 b_ = *reinterpret_cast<const float4*>(sD + rb + 8 * g + 4 * hh);
-                constexpr float LOG2E = 1.4426950408889634f;
-                const float la[4] = {a.x * LOG2E, a.y * LOG2E, a.z * LOG2E, a.w * LOG2E}, da[4] = {b_.x, b_.y, b_.z, b_.w};
+                const float4 a = *reinterpret_cast<const float4*>(sL + rb + 8 * g + 4 * hh);     // -lse log2(e); -inf for q >= len -> p = 0
+                float pr[4], d0 = dp[4 * g], d1 = dp[4 * g + 1], d2 = dp[4 * g + 2], d3 = dp[4 * g + 3];
+                exp4_mul(pr, s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], c, a.x, a.y, a.z, a.w, d0, d1, d2, d3);
+                dp[4 * g] = d0; dp[4 * g + 1] = d1; dp[4 * g + 2] = d2; dp[4 * g + 3] = d3;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e;
-                    bool ok = true;
-                    if (need_mask) {
-                        const int q = q0 + acc_row(r, hh);
-                        ok = key < len && q < len;
-                        if (p.win_left >= 0) ok = ok && key >= q - p.win_left;
-                        if (p.win_right >= 0) ok = ok && key <= q + p.win_right;
-                    }
-                    const float pr = ok ? __builtin_amdgcn_exp2f(s[r] * c - la[e]) : 0.f;   // lse2 = +inf for q >= len -> 0
-                    s[r] = pr;
-                    dp[r] = pr * (dp[r] - da[e]);
-                }
+                for (int e = 0; e < 4; ++e) s[4 * g + e] = pr[e];
             }
-            const bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
+            bf16x8 pb0 = pack8(s, 0), pb1 = pack8(s, 1), db0 = pack8(dp, 0), db1 = pack8(dp, 1);
+#ifdef SCONF_ATTN_STAMP
+            asm volatile("" : "+v"(pb0)); asm volatile("" : "+v"(pb1)); asm volatile("" : "+v"(db0)); asm volatile("" : "+v"(db1));
+#endif
+            STAMP(2);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
                 dvt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sG, L, rb, db, x32), pb0, dvt[db], 0, 0, 0);
@@ -1118,10 +1156,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dkdv8_kernel(const AttnParams p)
                 dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb, db, x32), db0, dkt[db], 0, 0, 0);
                 dkt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sQ, L, rb + 16, db, x32), db1, dkt[db], 0, 0, 0);
             }
+            STAMP(3);
         }
         dma_wait_all();                                // the next stage has landed (issued a stage of MFMAs ago)
         __syncthreads();
+        STAMP(4);
     }
+    STAMP_OUT(5);
     if (key < p.N) {
         if (p.rot_cos) store_t_rot<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5, p.rot_cos + (long)key * (D / 2), p.rot_sin + (long)key * (D / 2));
         else store_t<D>(dkt, p.dk + b * p.dk_sb + (long)key * p.dk_sn + h * p.dk_sh, p.scale, lane >> 5);
@@ -1153,7 +1194,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq_kernel(const AttnParams p)
     load_bfrags<D>(gf, gp, p.do_sn, q0, p.N, lane);
     float dlt = delta_from_frags<D>(gf, p.o + b * p.o_sb + h * p.o_sh, p.o_sn, q0, p.N, lane);
     if (qi >= len) dlt = 0.f;
-    if (hh == 0 && qi < p.N) p.delta[((long)b * p.H + h) * p.N + qi] = dlt;
+    // row statistics for the dK/dV kernel, in the form its MFMA chains and exponentials take them: -delta and -lse * log2(e)
+    // (-inf for rows past the sample's length: their probabilities come out 0)
+    if (hh == 0 && qi < p.N) {
+        const long si = ((long)b * p.H + h) * p.N + qi;
+        p.delta[si] = -dlt;
+        p.delta[(long)p.B * p.H * p.N + si] = -lse2;
+    }
     const LaneOffs<D> L(lane);
     const bool windowed = p.win_left >= 0 || p.win_right >= 0;
 
@@ -1239,9 +1286,20 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
     load_bfrags<D>(gf, gp, p.do_sn, q0, p.N, lane);
     float dlt = delta_from_frags<D>(gf, p.o + b * p.o_sb + h * p.o_sh, p.o_sn, q0, p.N, lane);
     if (qi >= len) dlt = 0.f;
-    if (hh == 0 && qi < p.N) p.delta[((long)b * p.H + h) * p.N + qi] = dlt;
+    // row statistics for the dK/dV kernel, in the form its MFMA chains and exponentials take them: -delta and -lse * log2(e)
+    // (-inf for rows past the sample's length: their probabilities come out 0)
+    if (hh == 0 && qi < p.N) {
+        const long si = ((long)b * p.H + h) * p.N + qi;
+        p.delta[si] = -dlt;
+        p.delta[(long)p.B * p.H * p.N + si] = -lse2;
+    }
     const LaneOffs<D> L(lane);
     const bool windowed = p.win_left >= 0 || p.win_right >= 0;
+    // keys this lane's query may see: [key_lo, key_lo + key_rng]
+    const int key_lo = p.win_left >= 0 ? max(0, qi - p.win_left) : 0;
+    const int key_hi = p.win_right >= 0 ? min(len - 1, qi + p.win_right) : len - 1;
+    const unsigned key_rng = key_hi >= key_lo ? (unsigned)(key_hi - key_lo) : 0u;
+    const bool key_none = key_hi < key_lo;
 
     const int kv_lo = p.win_left < 0 ? 0 : max(0, qb0 - p.win_left);
     const int kv_hi = min(len, p.win_right < 0 ? len : qb0 + 256 + p.win_right);
@@ -1265,11 +1323,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
     pin_frags(qf); pin_frags(gf);
     dma_wait_all();
     __syncthreads();
+    STAMP_DECL(8)
     for (int t = t_lo; t < t_hi; ++t) {
         const int cur = (t - t_lo) & 1;
         const char* sK = smem + cur * 2 * TB;
         const char* sV = sK + TB;
         if (t + 1 < t_hi) issue(t + 1, cur ^ 1);
+        STAMP(0);
         const int kv0 = t * KT;
 #pragma unroll
         for (int kt = 0; kt < KT / 32; ++kt) {
@@ -1281,34 +1341,60 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, L, kt * 32, st), qf[st], s, 0, 0, 0);    // S^T[key][q]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, L, kt * 32, st), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
             }
-            if (!(windowed || kv0 + KT > kv_hi)) {                               // ONE uniform branch, two straight-line bodies
+            STAMP(1);
+            if (windowed || kv0 + KT > kv_hi) {                                  // uniform: masked scores become -inf before the exponential (branch-free)
+                const unsigned t0 = (unsigned)(kv0 + kt * 32 + 4 * hh - key_lo);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt);
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kv0 + kt * 32 + acc_row(r, hh);
-                    bool ok = key < len;
-                    if (p.win_left >= 0) ok = ok && key >= qi - p.win_left;
-                    if (p.win_right >= 0) ok = ok && key <= qi + p.win_right;
-                    dp[r] = ok ? __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt) : 0.f;
-                }
+                for (int r = 0; r < 16; ++r) s[r] = (t0 + (unsigned)acc_row(r, 0) <= key_rng && !key_none) ? s[r] : -INFINITY;
             }
-            const bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt);
+            bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
+#ifdef SCONF_ATTN_STAMP
+            asm volatile("" : "+v"(d0)); asm volatile("" : "+v"(d1));
+#endif
+            STAMP(2);
 #pragma unroll
             for (int db = 0; db < D / 32; ++db) {
                 dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32, db), d0, dqt[db], 0, 0, 0);
                 dqt[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_tr<D>(sK, L, kt * 32 + 16, db), d1, dqt[db], 0, 0, 0);
             }
+            STAMP(3);
         }
         dma_wait_all();
         __syncthreads();
+        STAMP(4);
     }
+    STAMP_OUT(5);
     if (qi < p.N) {
         if (p.rot_cos) store_t_rot<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh, p.rot_cos + (long)qi * (D / 2), p.rot_sin + (long)qi * (D / 2));
         else store_t<D>(dqt, p.dq + b * p.dq_sb + (long)qi * p.dq_sn + h * p.dq_sh, p.scale, hh);
     }
 }
+
+#ifdef SCONF_ATTN_STAMP
+static unsigned long long* stamp_buf(long nwg, hipStream_t stream) {
+    static unsigned long long* sbuf = nullptr; static long scap = 0;
+    if (scap < nwg * 64) { if (sbuf) (void)hipFree(sbuf); (void)hipMalloc(&sbuf, nwg * 64 * 8); scap = nwg * 64; }
+    (void)hipMemsetAsync(sbuf, 0, nwg * 64 * 8, stream);
+    return sbuf;
+}
+static void stamp_report(const char* what, unsigned long long* sbuf, long nwg, double units_per_wave, int nseg, const char* const* nm, hipStream_t stream) {
+    if (!getenv("SCONF_ATTN_STAMP_PRINT")) return;
+    (void)hipStreamSynchronize(stream);
+    std::vector<unsigned long long> hb(nwg * 64);
+    (void)hipMemcpy(hb.data(), sbuf, nwg * 64 * 8, hipMemcpyDeviceToHost);
+    double sums[2][8] = {};
+    for (long w = 0; w < nwg * 8; ++w) for (int i = 0; i < 8; ++i) sums[(w & 7) >= 4][i] += (double)hb[w * 8 + i];
+    const double n = (double)nwg * 4 * units_per_wave;
+    for (int g = 0; g < 2; ++g) {
+        double tot = 0; for (int i = 0; i < nseg; ++i) tot += sums[g][i];
+        fprintf(stderr, "[%s stamps] waves %d-%d: cycles per unit %.0f:", what, 4 * g, 4 * g + 3, tot / n);
+        for (int i = 0; i < nseg; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], sums[g][i] / n, 100.0 * sums[g][i] / tot);
+        fprintf(stderr, "\n");
+    }
+}
+#endif
 
 void set_lds_attrs() {
     static bool done = false;
@@ -1393,7 +1479,7 @@ SCONF_API int sconf_attn_fwd(const void* q, const void* k, const void* v, void* 
     return 0;
 }
 
-// Backward.  delta: f32 (B,H,N) scratch.  dq/dk/dv: bf16 strided like q/k/v.  rot_cos / rot_sin (nullable, f32 (N, D/2)): q and k
+// Backward.  delta: f32 (2,B,H,N) scratch (the dQ kernel, which runs first, leaves -rowsum(dO * O) and -lse log2(e) there for the dK/dV kernel).  dq/dk/dv: bf16 strided like q/k/v.  rot_cos / rot_sin (nullable, f32 (N, D/2)): q and k
 // are rotary-rotated activations; dq and dk are then returned with the transpose of the rotation applied, i.e. as gradients of
 // the unrotated projections (apply_rotary_pos_emb backward, rotary_emb.py:61-73).
 SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
@@ -1432,7 +1518,13 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
         if (!(eq && eq[0] == '0') && N >= 256 && fits32) {
             static bool attr_set = false;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dq8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 128 * 256); attr_set = true; }
+#ifdef SCONF_ATTN_STAMP
+            p.stamps = stamp_buf(cdiv(N, 256) * H * B, stream);
+#endif
             hipLaunchKernelGGL((attn_bwd_dq8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), 4 * 128 * 256, stream, p);
+#ifdef SCONF_ATTN_STAMP
+            { static const char* nm[5] = {"dma-issue", "S|dP chains", "exp*", "dQ chain", "wait+barrier"}; stamp_report("dq8 (unit = 32 keys)", p.stamps, cdiv(N, 256) * H * B, (double)((N + 31) / 32), 5, nm, stream); }
+#endif
         } else
             hipLaunchKernelGGL((attn_bwd_dq_kernel<128>), grid, block, 4 * 64 * 256, stream, p);
         const char* e8 = getenv("SCONF_ATTN_DKDV8");           // "0" keeps the 4-wave dK/dV kernel (A/B, tests); read per call
@@ -1441,7 +1533,13 @@ SCONF_API int sconf_attn_bwd(const void* q, const void* k, const void* v, const 
             static bool attr_set = false;
             const int sh8 = 2 * (2 * 64 * 256 + 512) + 256 * 256;
             if (!attr_set) { (void)hipFuncSetAttribute((const void*)attn_bwd_dkdv8_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, sh8); attr_set = true; }
+#ifdef SCONF_ATTN_STAMP
+            p.stamps = stamp_buf(cdiv(N, 256) * H * B, stream);
+#endif
             hipLaunchKernelGGL((attn_bwd_dkdv8_kernel<128>), dim3((unsigned)(cdiv(N, 256) * H * B)), dim3(512), sh8, stream, p);
+#ifdef SCONF_ATTN_STAMP
+            { static const char* nm[5] = {"dma-issue", "S|dP chains", "exp*", "dV|dK chains", "wait+barrier"}; stamp_report("dkdv8 (unit = 32 queries)", p.stamps, cdiv(N, 256) * H * B, (double)((N + 31) / 32), 5, nm, stream); }
+#endif
         } else
             hipLaunchKernelGGL((attn_bwd_dkdv_kernel<128>), grid, block, 2 * (2 * 32 * 256 + 256) + 128 * 256, stream, p);
     } else {

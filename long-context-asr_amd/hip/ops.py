@@ -351,7 +351,7 @@ def attn_bwd(q, k, v, o, dout, lse, lengths, window=(-1, -1), scale: Optional[fl
         dk = torch.empty_like(dq); dv = torch.empty_like(dq)
     else:
         dq, dk, dv = out
-    delta = torch.empty(B, H, N, dtype=torch.float32, device=q.device)
+    delta = torch.empty(2, B, H, N, dtype=torch.float32, device=q.device)     # scratch: the dQ kernel leaves [-delta | -lse log2(e)] for the dK/dV kernel
     sc = float(scale) if scale is not None else D ** -0.5
     cos, sin = rot if rot is not None else (None, None)
     if cos is not None:
