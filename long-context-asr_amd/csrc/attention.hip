@@ -665,6 +665,16 @@ __device__ __forceinline__ void exp4_mul(float (&pr)[4], float s0, float s1, flo
         : "=&v"(pr[0]), "=&v"(pr[1]), "=&v"(pr[2]), "=&v"(pr[3]), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
         : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c), "v"(n0), "v"(n1), "v"(n2), "v"(n3));
 }
+//   d[j] = exp2(s[j] * c + nl) * (d[j] + nd)                                                           (backward, query on the lane)
+__device__ __forceinline__ void exp4_submul(float s0, float s1, float s2, float s3, float c, float nl, float nd, float& d0, float& d1, float& d2, float& d3) {
+    float e0, e1, e2, e3;
+    asm("v_fma_f32 %0, %8, %12, %13\n\tv_fma_f32 %1, %9, %12, %13\n\tv_fma_f32 %2, %10, %12, %13\n\tv_fma_f32 %3, %11, %12, %13\n\t"
+        "v_exp_f32 %0, %0\n\tv_exp_f32 %1, %1\n\tv_exp_f32 %2, %2\n\tv_exp_f32 %3, %3\n\t"
+        "v_add_f32 %4, %4, %14\n\tv_add_f32 %5, %5, %14\n\tv_add_f32 %6, %6, %14\n\tv_add_f32 %7, %7, %14\n\t"
+        "v_mul_f32 %4, %4, %0\n\tv_mul_f32 %5, %5, %1\n\tv_mul_f32 %6, %6, %2\n\tv_mul_f32 %7, %7, %3"
+        : "=&v"(e0), "=&v"(e1), "=&v"(e2), "=&v"(e3), "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+        : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(c), "v"(nl), "v"(nd));
+}
 // hipcc pads the wait states between an MFMA and a VALU instruction IT emits that reads the result (18 after a 16-pass MFMA); an asm
 // statement is not such an instruction.  The first asm statement that reads an MFMA result stands behind this guard: it makes
 // the accumulator opaque at this point and spends the wait states.
@@ -1331,9 +1341,13 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
         if (t + 1 < t_hi) issue(t + 1, cur ^ 1);
         STAMP(0);
         const int kv0 = t * KT;
-#pragma unroll
-        for (int kt = 0; kt < KT / 32; ++kt) {
-            f32x16 s, dp;
+        // Software-pipelined over the four 32-key blocks of the stage: the S | dP chains of block kt + 1 are issued BEFORE the
+        // exponentials of block kt, which then run under those MFMAs (two sets of score accumulators; stamps of the serial form:
+        // 16 MFMAs, then 750 cycles with the matrix pipe idle in both waves of the SIMD at once, then 8 MFMAs).
+        const bool masked = windowed || kv0 + KT > kv_hi;                        // uniform
+        const float nl = -lse2, nd = -dlt;
+        f32x16 s2[2], dp2[2];
+        auto chains = [&](int kt, f32x16& s, f32x16& dp) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
@@ -1341,14 +1355,26 @@ __global__ __launch_bounds__(512) void attn_bwd_dq8_kernel(const AttnParams p) {
                 s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sK, L, kt * 32, st), qf[st], s, 0, 0, 0);    // S^T[key][q]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(frag_row<D>(sV, L, kt * 32, st), gf[st], dp, 0, 0, 0);  // dP^T[key][q]
             }
-            STAMP(1);
-            if (windowed || kv0 + KT > kv_hi) {                                  // uniform: masked scores become -inf before the exponential (branch-free)
+        };
+        chains(0, s2[0], dp2[0]);
+        STAMP(1);
+#pragma unroll
+        for (int kt = 0; kt < KT / 32; ++kt) {
+            f32x16& s = s2[kt & 1];
+            f32x16& dp = dp2[kt & 1];
+            if (kt + 1 < KT / 32) chains(kt + 1, s2[(kt + 1) & 1], dp2[(kt + 1) & 1]);
+            if (masked) {                                                        // masked scores become -inf before the exponential (branch-free)
                 const unsigned t0 = (unsigned)(kv0 + kt * 32 + 4 * hh - key_lo);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) s[r] = (t0 + (unsigned)acc_row(r, 0) <= key_rng && !key_none) ? s[r] : -INFINITY;
             }
+            mfma_guard(s, dp);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) dp[r] = __builtin_amdgcn_exp2f(s[r] * c - lse2) * (dp[r] - dlt);
+            for (int g = 0; g < 4; ++g) {
+                float d0 = dp[4 * g], d1 = dp[4 * g + 1], d2 = dp[4 * g + 2], d3 = dp[4 * g + 3];
+                exp4_submul(s[4 * g], s[4 * g + 1], s[4 * g + 2], s[4 * g + 3], c, nl, nd, d0, d1, d2, d3);
+                dp[4 * g] = d0; dp[4 * g + 1] = d1; dp[4 * g + 2] = d2; dp[4 * g + 3] = d3;
+            }
             bf16x8 d0 = pack8(dp, 0), d1 = pack8(dp, 1);
 #ifdef SCONF_ATTN_STAMP
             asm volatile("" : "+v"(d0)); asm volatile("" : "+v"(d1));
