@@ -28,6 +28,7 @@
 #include "gemm_tile.h"
 #include <algorithm>
 #include <stdlib.h>
+#include <stdio.h>
 
 SCONF_API int sconf_num_cus(void);
 
@@ -378,6 +379,20 @@ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
     }
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
+// In-kernel time stamps (cdna_hip_programming.md section 7), DIAGNOSTIC build only (make EXTRA=-DSCONF_GEMM_STAMP; tools/gemm_stamp.py):
+// per wave, cycle sums of the fragment reads, the LDS-DMA issue, the counted wait, the waits at the two barriers of a phase, the
+// MFMA clusters and the epilogue.  Nothing of it exists in the product build.
+#ifdef SCONF_GEMM_STAMP
+__device__ unsigned long long g_gemm_stamps[256 * 8 * 8];
+#define GSTAMP_DECL unsigned long long st_acc_[8] = {}, st_last_ = 0; { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last_ = t_; }
+#define GSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                       __builtin_amdgcn_sched_barrier(0); st_acc_[i] += t_ - st_last_; st_last_ = t_; } while (0)
+#define GSTAMP_OUT do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 256) for (int i_ = 0; i_ < 8; ++i_) g_gemm_stamps[((long)blockIdx.x * 8 + (threadIdx.x >> 6)) * 8 + i_] = st_acc_[i_]; } while (0)
+#else
+#define GSTAMP_DECL
+#define GSTAMP(i)
+#define GSTAMP_OUT
+#endif
 // leave the 4 youngest half-tiles in flight: 2 + 2 + 2 + JH DMA instructions per wave
 template <int JH> __device__ __forceinline__ void wait_window(bool streaming) {
     if (!streaming) VMCNT(0);
@@ -442,6 +457,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 
     int cur = 0;
     bf16x8 fa[4][2], blo[2][2], bhi[JH][2];
+    GSTAMP_DECL
     while (true) {
         if (wr) __builtin_amdgcn_s_barrier();         // stagger the second wave row by one barrier
         for (int kt = 0; kt < cit.nkt; ++kt) {
@@ -464,9 +480,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int kk = 0; kk < 2; ++kk) fa[i][kk] = frag_a<KS>(buf, wr, i, kk, lane);
                 }
             }
+            GSTAMP(6);
             issue_b(pc, 1);
+            GSTAMP(7);
             wait_window<JH>(pc.valid);
+            GSTAMP(0);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(1);
             if constexpr (KS) {
                 LGKM0();
 #pragma unroll
@@ -486,7 +506,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int j = 0; j < 2; ++j)
                         acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], fa[i][kk], acc[0][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            GSTAMP(2);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(3);
             // ---- q1: B-hi -> acc[0][.][2..3] ---------------------------------------------------------------------
 #pragma unroll
             for (int j = 0; j < JH; ++j) {
@@ -496,9 +518,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int kk = 0; kk < 2; ++kk) bhi[j][kk] = frag_b<KS, JH == 1>(buf + 3 * HT, wc, j, kk, lane);
                 }
             }
+            GSTAMP(6);
             issue_a(pc, 1);
+            GSTAMP(7);
             wait_window<JH>(pc.valid);
+            GSTAMP(0);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(1);
             if constexpr (KS) {
                 LGKM0();
 #pragma unroll
@@ -515,7 +541,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int j = 0; j < JH; ++j)
                         acc[0][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[j][kk], fa[i][kk], acc[0][i][2 + j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            GSTAMP(2);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(3);
             // ---- q2: A-hi -> acc[1][.][2..3] ---------------------------------------------------------------------
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -526,9 +554,13 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                 }
             }
             pc.advance(p, sc);
+            GSTAMP(6);
             issue_a(pc, 0);
+            GSTAMP(7);
             wait_window<JH>(pc.valid);
+            GSTAMP(0);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(1);
             if constexpr (KS) {
                 LGKM0();
 #pragma unroll
@@ -545,11 +577,17 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int j = 0; j < JH; ++j)
                         acc[1][i][2 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bhi[j][kk], fa[i][kk], acc[1][i][2 + j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            GSTAMP(2);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(3);
             // ---- q3: (B-lo still in registers) -> acc[1][.][0..1] ------------------------------------------------
+            GSTAMP(6);
             issue_b(pc, 0);
+            GSTAMP(7);
             wait_window<JH>(pc.valid);
+            GSTAMP(0);
             __builtin_amdgcn_s_barrier();
+            GSTAMP(1);
             __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
@@ -559,7 +597,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
                     for (int j = 0; j < 2; ++j)
                         acc[1][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(blo[j][kk], fa[i][kk], acc[1][i][j], 0, 0, 0);
             __builtin_amdgcn_s_setprio(0);
+            GSTAMP(2);
             if (!(wr && last)) __builtin_amdgcn_s_barrier();   // the lagging row goes straight into its epilogue
+            GSTAMP(3);
             cur ^= 1;
         }
         // ---- epilogue: both wave rows concurrently; one specialised, contiguous code path per (activation, residual) ------
@@ -582,12 +622,15 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
         if (st) { st[2] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); st[3] = __builtin_amdgcn_s_memtime(); }
         ++probe_item;
 #endif
+        GSTAMP(4);                                    // epilogue (+ accumulator clears)
         __builtin_amdgcn_s_barrier();                 // re-align the two wave rows
+        GSTAMP(5);
         cv += gridDim.x;
         if (cv >= sc.total) break;
         cit = item_coords(p, sc, cv);
     }
     VMCNT(0);
+    GSTAMP_OUT;
 }
 
 // ---- 256x192 tile, NT, THREE phases per K-tile -------------------------------------------------------------------------
@@ -790,5 +833,23 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
     else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
     else               hipLaunchKernelGGL(gemm192_kernel, grid, block, shmem, stream, p);
     SCONF_LAUNCH_OK("sconf_gemm_bf16 (256-row tile)");
+#ifdef SCONF_GEMM_STAMP
+    if (getenv("SCONF_GEMM_STAMP_PRINT") && (layout == 2 || w == 256)) {
+        (void)hipStreamSynchronize(stream);
+        static unsigned long long hb[256 * 8 * 8];
+        (void)hipMemcpyFromSymbol(hb, HIP_SYMBOL(g_gemm_stamps), sizeof(hb));
+        const int nwg = std::min(total, 256);
+        const double ktiles = (double)total / nwg * (p.k_per_split / TK);           // K-tiles per workgroup
+        static const char* nm[8] = {"vmcnt wait", "barrier 1", "MFMA cluster", "barrier 2", "epilogue", "re-align", "frag reads", "DMA issue"};
+        for (int g = 0; g < 2; ++g) {
+            double sums[8] = {}, tot = 0;
+            for (int wg = 0; wg < nwg; ++wg) for (int wv = 4 * g; wv < 4 * g + 4; ++wv) for (int i = 0; i < 8; ++i) sums[i] += (double)hb[(wg * 8 + wv) * 8 + i];
+            for (int i = 0; i < 8; ++i) tot += sums[i];
+            fprintf(stderr, "[gemm256 %s M=%d N=%d K=%d stamps] wave row %d: cycles per K-tile %.0f:", layout == 2 ? "TN" : "NT", p.M, p.N, p.K, g, tot / (nwg * 4.0 * ktiles));
+            for (int i = 0; i < 8; ++i) fprintf(stderr, "  %s %.0f (%.1f%%)", nm[i], sums[i] / (nwg * 4.0 * ktiles), 100.0 * sums[i] / tot);
+            fprintf(stderr, "\n");
+        }
+    }
+#endif
     return 0;
 }
