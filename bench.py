@@ -43,7 +43,9 @@ CONFIGS = {
                name='6L/768D/6H SConformerXL, seq=16384, rotary theta=1.5M'),
     'c2': dict(model=dict(vocab_size=4095, n_layers=6, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
-                          default_norm='layer_norm', bias_in_ff=False), T=1024, batch=64,
+                          default_norm='layer_norm', bias_in_ff=False), T=1024, batch=1024,
+               # the reference trains 1024-frame chunks 352 to an 80 GB GPU (exp/configs/README.md:85-93) = 1267 to 288 GB; 1024 keeps
+               # every GEMM in whole rounds of 256-row tiles (66 GiB peak).  (B = 64: 16 ms/step, 4.1 M frames/s - launch-bound.)
                name='6L/768D/6H SConformerXL, seq=1024'),
     'c1': dict(model=dict(vocab_size=4095, n_layers=6, d_model=256, n_heads=8, head_dim=32, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
