@@ -29,6 +29,18 @@
 
 namespace {
 
+#ifdef CTC_STAMP
+__device__ unsigned long long g_ctc_stamps[16 * 8];
+#define CSTAMP_DECL unsigned long long st_acc_[8] = {}, st_last_ = 0; { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); st_last_ = t_; }
+#define CSTAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                      __builtin_amdgcn_sched_barrier(0); st_acc_[i] += t_ - st_last_; st_last_ = t_; } while (0)
+#define CSTAMP_OUT do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) for (int i_ = 0; i_ < 8; ++i_) g_ctc_stamps[(threadIdx.x >> 6) * 8 + i_] = st_acc_[i_]; } while (0)
+#else
+#define CSTAMP_DECL
+#define CSTAMP(i)
+#define CSTAMP_OUT
+#endif
+
 // log(e^a + e^b + e^c): the largest term contributes exactly 1, so only the median and the minimum need an exponential
 // (v_max3 / v_med3 / v_min3 pick them without branches) - 2 exp + 1 log on the serial chain instead of 3 + 1.
 __device__ __forceinline__ float lse3(float a, float b, float c) {
@@ -37,12 +49,36 @@ __device__ __forceinline__ float lse3(float a, float b, float c) {
     const float md = __builtin_amdgcn_fmed3f(a, b, c), mn = fminf(a, fminf(b, c));
     return m + __logf(1.f + __expf(md - m) + __expf(mn - m));
 }
-// The same with f64 state: maximum and differences in f64, exponentials and logarithm in f32 (arguments <= 0, result in [0, log 3]:
-// ~1e-7 absolute whatever the magnitude of a, b, c).  The term of the maximum is exp(0) = 1 exactly.
-__device__ __forceinline__ double lse3(double a, double b, double c) {
-    const double m = fmax(a, fmax(b, c));
-    if (m == -INFINITY) return -INFINITY;
-    return m + (double)__logf(__expf((float)(a - m)) + __expf((float)(b - m)) + __expf((float)(c - m)));
+// The f64-state form works in LOG2 units (v_exp_f32 / v_log_f32 are base-2: no multiplies, and none of the denormal-range fix-ups
+// of __expf / __logf - the arguments are <= 0 and the sum is in [1, 3]).  Maximum and differences in f64, the transcendental part in
+// f32: ~1e-7 absolute whatever the magnitude of a, b, c.  "Unreachable" is NEG_BIG (finite), not -inf: three unreachable inputs give
+// NEG_BIG + log2(3) = NEG_BIG (absorbed) without a special case, and (float)NEG_BIG = -inf is what the stored rows show.
+constexpr double NEG_BIG = -1e300;
+constexpr double LOG2E_D = 1.4426950408889634, LN2_D = 0.6931471805599453;
+__device__ __forceinline__ double max_f64(double a, double b) {          // fmax() canonicalises its inputs first (3 instructions)
+    double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r;
+}
+__device__ __forceinline__ double max_lt(double a, double b) { return max_f64(a, b); }
+__device__ __forceinline__ float max_lt(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double lse3_log2(double a, double b, double c) {
+    const double m = max_f64(a, max_f64(b, c));
+    const float s = __builtin_amdgcn_exp2f((float)(a - m)) + __builtin_amdgcn_exp2f((float)(b - m)) + __builtin_amdgcn_exp2f((float)(c - m));
+    return m + (double)__builtin_amdgcn_logf(s);
+}
+__device__ __forceinline__ float lse3_log2(float a, float b, float c) {  // f32 state (lattices too long for the LDS in f64)
+    const float m = fmaxf(a, fmaxf(b, c));
+    return m + __builtin_amdgcn_logf(__builtin_amdgcn_exp2f(a - m) + __builtin_amdgcn_exp2f(b - m) + __builtin_amdgcn_exp2f(c - m));
+}
+// Maximum over the wave by DPP (no LDS round trips): quad swaps, half-row and row mirrors, then the four row maxima by readlane.
+__device__ __forceinline__ float wave_max_dpp(float v) {
+    int x;
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));   // quad_perm [1,0,3,2]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true);  v = fmaxf(v, __int_as_float(x));   // quad_perm [2,3,0,1]
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));   // row_half_mirror
+    x = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true); v = fmaxf(v, __int_as_float(x));   // row_mirror
+    const int iv = __float_as_int(v);
+    return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 0)), __int_as_float(__builtin_amdgcn_readlane(iv, 16))),
+                 fmaxf(__int_as_float(__builtin_amdgcn_readlane(iv, 32)), __int_as_float(__builtin_amdgcn_readlane(iv, 48))));
 }
 
 // One workgroup per (sample, frame): the frame's whole log-prob row is streamed into LDS with 16-byte loads and the 2S+1 lattice
@@ -97,14 +133,20 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict
 }
 
 // One workgroup per (sample, direction).  MAXS = max lattice states per thread; LT = type of the recursion's state (double; float
-// only for lattices that do not fit the LDS in f64).
+// only for lattices that do not fit the LDS in f64).  The recursion runs in log2 units relative to nothing (absolute, in LT); what
+// is STORED for the gradient pass is natural-log, f32, relative to the frame's offset A_t (f64, written to offs), which follows the
+// maximum of the stored row every 4th frame.  The serial step is: LDS reads of three neighbours -> lse3 -> LDS write -> barrier.
+//  * the barrier is a raw s_barrier behind `s_waitcnt lgkmcnt(0)`: __syncthreads() also waits for the frame's global stores to be
+//    acknowledged (vmcnt(0)), a memory round trip per frame that nothing depends on;
+//  * a wave whose states are all unreachable at this frame (s > 2i + 1) or can no longer reach the end (s < L - 2 (T - i)) skips the
+//    arithmetic and stores -inf (a quarter of the lattice at T = 4 S).
 template <int MAXS, typename LT>
 __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __restrict__ lpg, const int* __restrict__ targets,
                                                              const int* __restrict__ in_len, const int* __restrict__ tg_len,
                                                              float* __restrict__ alpha, float* __restrict__ beta,
                                                              float* __restrict__ nll, double* __restrict__ offs,
                                                              int B, int N, int C, int Smax, int Lmax, int blank) {
-    extern __shared__ double lat_raw[];                 // LT [2][Lmax + 2], two leading -inf guard cells per row; then float [2][16] wave maxima
+    extern __shared__ double lat_raw[];                 // LT [2][W]; then float [16] wave maxima
     LT* lat = reinterpret_cast<LT*>(lat_raw);
     const int b = blockIdx.x % B;
     const bool is_beta = blockIdx.x >= B;
@@ -114,9 +156,10 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     double* nll64 = offs + 2L * B * N;
     const float* lg = lpg + (long)b * N * Lmax;
     const int nt = blockDim.x, tid = threadIdx.x;
-    const int W = Lmax + 2;
-    float* wm = reinterpret_cast<float*>(lat + 2 * W);  // [2][16] per-wave maxima of the (stored, relative) row just written
-    const int nw = nt >> 6, wave = tid >> 6;
+    const int W = Lmax + MAXS + 2;                      // two guard cells in front, MAXS cells of slack behind
+    float* wm = reinterpret_cast<float*>(lat_raw + (((size_t)2 * W * sizeof(LT) / 8 + 2) & ~(size_t)1));   // 16-byte aligned, behind the rows
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LT NEG = sizeof(LT) == 8 ? (LT)NEG_BIG : (LT)-1e30f;
     if (T <= 0) { if (!is_beta && tid == 0) { nll[b] = INFINITY; nll64[b] = INFINITY; } return; }
     // Inputs torch.nn.CTCLoss rejects on the host (input_length > N, target_length > Smax, a label outside [0, C)): the lengths
     // live on the device here, so the sample is poisoned instead - nll = NaN, its gradient rows NaN (ctc_grad_kernel), which the
@@ -127,11 +170,15 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
         if (__syncthreads_or(bad)) { if (!is_beta && tid == 0) { nll[b] = NAN; nll64[b] = NAN; } return; }
     }
 
-    // per-state constants in MIRRORED coordinates sp (beta walks the reversed lattice)
+    // A thread owns MAXS ADJACENT states, in MIRRORED coordinates sp (beta walks the reversed lattice): its MAXS + 2 inputs are one
+    // contiguous LDS read, a wave covers one contiguous range (so the band test is per wave), and the MAXS recursions are
+    // independent straight-line chains the compiler interleaves (the step is bound by the LATENCY of one chain - LDS read, f64
+    // max / differences, three exponentials, a logarithm, f64 adds, LDS write - not by issue).
+    const int sp0 = tid * MAXS, cnt = min(max(L - sp0, 0), MAXS);
     bool skip_ok[MAXS];
 #pragma unroll
     for (int k = 0; k < MAXS; ++k) {
-        const int sp = tid + k * nt;
+        const int sp = sp0 + k;
         skip_ok[k] = false;
         if (sp < L && sp >= 2) {
             const int s = is_beta ? L - 1 - sp : sp;
@@ -141,27 +188,47 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             }
         }
     }
-    for (int i = tid; i < 2 * W; i += nt) lat[i] = (LT)-INFINITY;
+    for (int i = tid; i < 2 * W; i += nt) lat[i] = NEG;
+    if (tid < 16) wm[tid] = -INFINITY;                   // slots of waves that do not exist stay -inf
+    __syncthreads();
+    if (tid == 0) lat[W + 2] = (LT)0;                    // virtual frame -1 (row 1): all mass in state 0, so frame 0 is the general step
     __syncthreads();
 
     float pf[4][MAXS], nx[4][MAXS];
+    // Unconditional loads from clamped (always valid) addresses: a load inside a branch is waited for inside that branch (vmcnt(0),
+    // in order behind every store in flight) - eight serial memory round trips per group instead of a prefetch.  What the clamped
+    // loads bring for frames >= T or states >= L is never used.
     auto load_group = [&](float (&dst)[4][MAXS], int i0) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int i = i0 + j;
+            const int i = min(i0 + j, T - 1);
             const int t = is_beta ? T - 1 - i : i;
 #pragma unroll
             for (int k = 0; k < MAXS; ++k) {
-                const int sp = tid + k * nt;
+                const int sp = min(sp0 + k, L - 1);
                 const int s = is_beta ? L - 1 - sp : sp;
-                dst[j][k] = (i < T && sp < L) ? lg[(long)t * Lmax + s] : 0.f;
+                dst[j][k] = lg[(long)t * Lmax + s];
             }
         }
     };
     load_group(pf, 0);
-    double A = 0.0;                                      // offset of the stored row: the sum of the maxima of the previous stored rows
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(pf[j][k], -1e30f);
+    double A = 0.0;                                      // offset of the stored rows, log2 units
+    CSTAMP_DECL
+    const int w0 = wave * 64 * MAXS, w1 = w0 + 64 * MAXS - 1;   // the wave's range of states
     for (int i0 = 0; i0 < T; i0 += 4) {
         load_group(nx, i0 + 4);                          // prefetch the next 4 time steps
+        CSTAMP(4);
+        if (i0 > 0) {                                    // the offset follows the maximum of the row stored at frame i0 - 1: one LDS round trip
+            const float4* pm = reinterpret_cast<const float4*>(wm);
+            const float4 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
+            const float m = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                                  fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
+            if (m > -1e30f) A += (double)m;
+        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int i = i0 + j;
@@ -169,43 +236,77 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 const int t = is_beta ? T - 1 - i : i;
                 LT* cur = lat + (i & 1) * W + 2;
                 const LT* prev = lat + ((i & 1) ^ 1) * W + 2;
-                // this step's offset moves by the maximum of the previous STORED row (its wave maxima were published before the barrier)
-                if (i > 0) {
-                    const float* pm = wm + ((i & 1) ^ 1) * 16;
-                    float m = pm[0];
-                    for (int w = 1; w < nw; ++w) m = fmaxf(m, pm[w]);
-                    if (m != -INFINITY) A += (double)m;
-                }
-                if (tid == 0) off_out[t] = A;
+                if (tid == 0) off_out[t] = A * LN2_D;
+                const int hi = 2 * i + 1, lo = L - 2 * (T - i);       // live band of (mirrored) states at this frame
                 float mine = -INFINITY;
+                float* orow = out + (long)t * Lmax;
+                if (w0 <= hi && w1 >= lo) {                           // wave-uniform
+                    if (cnt > 0) {
+                        LT pv[MAXS + 2];
 #pragma unroll
-                for (int k = 0; k < MAXS; ++k) {
-                    const int sp = tid + k * nt;
-                    if (sp < L) {
-                        LT v;
-                        if (i == 0) v = (sp < 2) ? (LT)pf[j][k] : (LT)-INFINITY;
-                        else v = lse3(prev[sp], prev[sp - 1], skip_ok[k] ? prev[sp - 2] : (LT)-INFINITY) + (LT)pf[j][k];
-                        cur[sp] = v;
-                        const float st = (float)((double)v - A);                 // what the gradient pass reads: relative to the frame's offset
-                        out[(long)t * Lmax + (is_beta ? L - 1 - sp : sp)] = st;
-                        mine = fmaxf(mine, st);
+                        for (int q = 0; q < MAXS + 2; ++q) pv[q] = prev[sp0 - 2 + q];
+                        CSTAMP(0);
+                        // The MAXS recursions stage by stage (sched_barrier pins the order): every stage is MAXS independent
+                        // instructions, so a chain's latency (f64 max / differences, exponentials, logarithm) is covered by its siblings.
+                        LT c[MAXS], m[MAXS], base[MAXS];
+                        float e0[MAXS], e1[MAXS], e2[MAXS];
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) { c[k] = skip_ok[k] ? pv[k] : NEG; m[k] = max_lt(pv[k + 2], pv[k + 1]); }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) m[k] = max_lt(m[k], c[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) {
+                            e0[k] = (float)(pv[k + 2] - m[k]); e1[k] = (float)(pv[k + 1] - m[k]); e2[k] = (float)(c[k] - m[k]);
+                            base[k] = sizeof(LT) == 8 ? (LT)__builtin_fma((double)pf[j][k], LOG2E_D, (double)m[k]) : (LT)(m[k] + pf[j][k] * (float)LOG2E_D);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) { e0[k] = __builtin_amdgcn_exp2f(e0[k]); e1[k] = __builtin_amdgcn_exp2f(e1[k]); e2[k] = __builtin_amdgcn_exp2f(e2[k]); }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) e0[k] = __builtin_amdgcn_logf(e0[k] + e1[k] + e2[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        CSTAMP(1);
+#pragma unroll
+                        for (int k = 0; k < MAXS; ++k) {
+                            const LT v = base[k] + (LT)e0[k];
+                            if (k < cnt) cur[sp0 + k] = v;
+                            const float rel = (float)((double)v - A); // log2 units, relative to the frame's offset
+                            if (k < cnt) {
+                                orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = rel * (float)LN2_D;
+                                mine = fmaxf(mine, rel);
+                            }
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < MAXS; ++k)
+                        if (k < cnt) { cur[sp0 + k] = NEG; orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = -INFINITY; }
                 }
-                mine = wave_max(mine);
-                if ((tid & 63) == 0) wm[(i & 1) * 16 + wave] = mine;
-                __syncthreads();
+                if (j == 3) {
+                    mine = wave_max_dpp(mine);
+                    if ((tid & 63) == 0) wm[wave] = mine;
+                }
+                CSTAMP(2);
+                asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+                CSTAMP(3);
             }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int k = 0; k < MAXS; ++k) pf[j][k] = nx[j][k];
+            for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(nx[j][k], -1e30f);            // an emission of -inf must stay finite in the recursion
+        CSTAMP(5);
     }
+    CSTAMP_OUT;
     if (!is_beta && tid == 0) {
         const LT* last = lat + ((T - 1) & 1) * W + 2;
-        const double v = -(double)lse3(last[L - 1], L > 1 ? last[L - 2] : (LT)-INFINITY, (LT)-INFINITY);
-        nll64[b] = v;
-        nll[b] = (float)v;
+        const double v = -(double)lse3_log2(last[L - 1], L > 1 ? last[L - 2] : NEG, NEG) * LN2_D;
+        const bool none = v > (sizeof(LT) == 8 ? 1e290 : 1e29);          // no alignment reaches the end: +inf, as torch's zero_infinity=False
+        nll64[b] = none ? (double)INFINITY : v;
+        nll[b] = none ? INFINITY : (float)v;
     }
 }
 
@@ -357,7 +458,7 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     SCONF_REQUIRE(offs != nullptr, "%s: the f64 offset workspace (2*B*N + B doubles) is required", who);
     const int Lmax = (int)(2 * Smax + 1);
     SCONF_REQUIRE(blank >= 0 && blank < C, "%s: blank %d out of range", who, blank);
-    SCONF_REQUIRE((long)(Lmax + 2) * 8 + 128 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);   // (f32 state)
+    SCONF_REQUIRE((long)(Lmax + 18) * 8 + 144 <= 160 * 1024, "%s: lattice of %d states does not fit LDS", who, Lmax);   // (f32 state)
     SCONF_REQUIRE(C % 4 == 0 && C * 4 <= 64 * 1024, "%s: C must be a multiple of 4 and one row must fit LDS (%ld classes)", who, (long)C);
     const dim3 gg((unsigned)std::min<long>(B * N, 65536));
     if (from_logits) hipLaunchKernelGGL(ctc_gather_kernel<true>, gg, dim3(256), (size_t)C * 4, stream, in, targets, input_lengths, target_lengths,
@@ -367,8 +468,9 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
-    const bool f64_state = ((size_t)2 * (Lmax + 2)) * 8 + 128 <= 160 * 1024;   // else f32 state (lattices of more than 10230 states)
-    const size_t sh = ((size_t)2 * (Lmax + 2)) * (f64_state ? 8 : 4) + 128;
+    const int spt_pad = spt <= 1 ? 1 : spt <= 2 ? 2 : spt <= 4 ? 4 : spt <= 8 ? 8 : 16;     // MAXS of the instantiation taken below
+    const bool f64_state = ((size_t)2 * (Lmax + spt_pad + 2)) * 8 + 144 <= 160 * 1024;        // else f32 state (lattices of more than ~10200 states)
+    const size_t sh = ((size_t)2 * (Lmax + spt_pad + 2)) * (f64_state ? 8 : 4) + 144;
     SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
 #define L2(MS, LT) do { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
@@ -378,6 +480,18 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
 #undef L2
 #undef L
+#ifdef CTC_STAMP
+    if (getenv("SCONF_CTC_STAMP_PRINT")) {
+        (void)hipStreamSynchronize(stream);
+        unsigned long long h[16 * 8];
+        (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ctc_stamps), sizeof(h));
+        for (int w = 0; w < nt / 64; ++w) {
+            fprintf(stderr, "[ctc stamps] wave %2d:", w);
+            for (int i = 0; i < 6; ++i) fprintf(stderr, " %8.1f", (double)h[w * 8 + i] / (double)N);
+            fprintf(stderr, "   (memtime ticks per frame: lds-read, math, write+store, barrier, prefetch-issue, prefetch-wait)\n");
+        }
+    }
+#endif
     return 0;
 }
 

@@ -430,6 +430,27 @@ def test_attention_fwd_bwd(ops, case, dkdv8, monkeypatch):
     close(dq, dqr, name='dq', tol=2e-2); close(dk, dkr, name='dk', tol=2e-2); close(dv, dvr, name='dv', tol=2e-2)
 
 
+@pytest.mark.parametrize('boost', [1.9, 30.0])
+def test_attention_forward_fixed_reference_and_its_careful_redo(ops, boost):
+    """The 8-wave forward keeps the exponent reference of a query row at the maximum of its FIRST 64 scores.  A key far down the
+    row that beats it by ~36 (boost 1.9: scaled score 128 * 1.9^2 / sqrt(128) = 41; no rescale, P up to e^36, still finite) must
+    give the same quotient; one that beats it by ~1e4 (boost 30) overflows the f32 exponent: the workgroup must notice (non-finite l / O) and redo its
+    tile with the running-maximum loop.  Backward on the same inputs (it starts from the LSE, so it has no such path)."""
+    B, N, H, D = 2, 640, 2, 128
+    q, k, v = rnd(B, N, H, D), rnd(B, N, H, D, seed=1), rnd(B, N, H, D, seed=2)
+    q[0, 300, 0, :] = boost; k[0, 411, 0, :] = boost            # score 128 * boost^2 / sqrt(128) at key 411 of query row 300
+    q[1, 77, 1, :] = -boost; k[1, 600, 1, :] = -boost
+    o, lse = ops.attn_fwd(dev(q), dev(k), dev(v), None, (-1, -1))
+    orf, lser = R.attn_fwd(q, k, v, None, (-1, -1))
+    assert bool(torch.isfinite(o.float()).all()) and bool(torch.isfinite(lse).all())
+    close(o, orf, name=f'attn o (planted score, boost {boost})')
+    assert float(((lse.cpu() - lser).abs() / lser.abs().clamp_min(1.0)).max()) < 2e-3, 'lse'
+    do = rnd(B, N, H, D, seed=3)
+    dq, dk, dv = ops.attn_bwd(dev(q), dev(k), dev(v), o, dev(do), lse, None, (-1, -1))
+    dqr, dkr, dvr = R.attn_bwd(q, k, v, orf, do, lser, None, (-1, -1))
+    close(dq, dqr, name='dq', tol=2e-2); close(dk, dkr, name='dk', tol=2e-2); close(dv, dvr, name='dv', tol=2e-2)
+
+
 def test_attention_strided_views(ops):
     """q,k,v as strided views of one packed (B,N,3,H,D) buffer — FlashSelfAttention's qkv-packed input."""
     B, N, H, D = 2, 150, 2, 128
