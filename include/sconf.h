@@ -20,7 +20,8 @@ typedef struct ihipStream_t* sconf_stream_t; /* == hipStream_t */
 
 enum { SCONF_F32 = 0, SCONF_BF16 = 1 };
 enum { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4,
-       SCONF_ACT_GELU_DSAVE = 5 /* out = gelu(v), pre = gelu'(v) */, SCONF_ACT_MULAUX = 6 /* out = v * aux */ };
+       SCONF_ACT_GELU_DSAVE = 5 /* out = gelu(v), pre = gelu'(v) */, SCONF_ACT_MULAUX = 6 /* out = v * aux */,
+       SCONF_ACT_SMAXBWD = 7 /* out = (v - rowv[m]) * aux: softmax backward, sconf_gemm_softmax_bwd only */ };
 enum { SCONF_GEMM_NT = 0, SCONF_GEMM_NN = 1, SCONF_GEMM_TN = 2 };
 enum { SCONF_NORM_LAYER = 0, SCONF_NORM_RMS = 1, SCONF_NORM_RMS_APEX = 2 };
 
@@ -47,6 +48,18 @@ int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C, int64_t M
 int sconf_gemm_qkv_rotary(const void* A, const void* W, void* C, int64_t M, int64_t K, int64_t H, int64_t D,
                           int64_t lda, int64_t ldb, const float* bias, const float* cos_tab, const float* sin_tab,
                           int64_t seq_len, sconf_stream_t stream);
+
+/* Softmax backward inside the dgrad GEMM of the self-conditioning reprojection (sconformer_xl.py:241-243, backward of
+ * x + reprojection(softmax(ff(norm(x))))): dl (M, V) bf16 = probs * (dy Wt^T - delta), dy (M, K) bf16, Wt (V, K) bf16 (the transposed
+ * reprojection weight), probs (M, V) bf16, delta (M) f32 = sum_v probs * (dy Wt^T) - obtained WITHOUT that product as
+ * sconf_rowdot(dy, saved reprojection output before residual, reprojection bias).  colslab (2 M / 256, V) f32 receives column sums of dl
+ * per (256-row panel, wave row): sconf_colsum over it gives the decoder bias gradient.  Returns 2 (nothing launched) when the shape does
+ * not take the 256-row NT kernel (M % 256, V % 256 or 192, K % 64): the caller then uses sconf_gemm_bf16 + sconf_softmax_bwd. */
+int sconf_gemm_softmax_bwd(const void* dy, const void* Wt, const void* probs, const float* delta, void* dl, float* colslab,
+                           int64_t M, int64_t V, int64_t K, int64_t lddy, int64_t ldw, int64_t ldp, sconf_stream_t stream);
+/* out[m] = sum_c a[m][c] * (b[m][c] - bias[c])   (a, b bf16 (M, d); bias f32 (d) or null; d % 8 == 0) */
+int sconf_rowdot(const void* a, const void* b, const float* bias, float* out, int64_t M, int64_t d, int64_t lda, int64_t ldb,
+                 sconf_stream_t stream);
 int sconf_gemm_num_splits(int64_t K, int split_k);
 /* Which kernel sconf_gemm_bf16 runs for a problem (bookkeeping for benchmarks): 0 = 128x128-tile kernel, 1 / 2 = 256-row NT
  * kernel with 256 / 192-wide tiles, 3 = 256x256 TN kernel; -1 = invalid arguments. */

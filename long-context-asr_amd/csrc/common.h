@@ -23,7 +23,8 @@ int sconf_set_error(const char* fmt, ...);
 enum SconfDtype { SCONF_F32 = 0, SCONF_BF16 = 1 };
 enum SconfAct { SCONF_ACT_NONE = 0, SCONF_ACT_GELU = 1, SCONF_ACT_SILU = 2, SCONF_ACT_DGELU = 3, SCONF_ACT_DSILU = 4,
                 SCONF_ACT_GELU_DSAVE = 5,   // out = gelu(v); `pre` receives gelu'(v) (what the backward multiplies by)
-                SCONF_ACT_MULAUX = 6 };     // out = v * aux
+                SCONF_ACT_MULAUX = 6,       // out = v * aux
+                SCONF_ACT_SMAXBWD = 7 };    // out = (v - rowv[m]) * aux (softmax backward; sconf_gemm_softmax_bwd only)
 
 
 // ---- device helpers --------------------------------------------------------------------------

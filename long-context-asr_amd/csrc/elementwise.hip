@@ -390,6 +390,36 @@ SCONF_API int sconf_softmax_fwd(int mode, const void* x, int x_dtype, void* y, i
 }
 
 constexpr int SOFTMAX_BWD_SLABS = 2048;             // workgroups (= column-sum slabs) of the fused softmax backward
+// out[m] = sum_c a[m][c] * (b[m][c] - bias[c]): one wave per row, 8 bf16 per lane and load (d % 8 == 0).
+namespace {
+__global__ __launch_bounds__(256) void rowdot_kernel(const bf16* __restrict__ a, const bf16* __restrict__ b, const float* __restrict__ bias,
+                                                     float* __restrict__ out, long M, int d, long lda, long ldb) {
+    const int lane = threadIdx.x & 63;
+    for (long m = (long)blockIdx.x * 4 + (threadIdx.x >> 6); m < M; m += (long)gridDim.x * 4) {
+        float s = 0.f;
+        for (int c = lane * 8; c < d; c += 512) {
+            float x[8], y[8], z[8];
+            load8(a + m * lda + c, x); load8(b + m * ldb + c, y);
+            if (bias) load8(bias + c, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s += x[e] * (y[e] - (bias ? z[e] : 0.f));
+        }
+        s = wave_sum(s);
+        if (lane == 0) out[m] = s;
+    }
+}
+}  // namespace
+
+SCONF_API int sconf_rowdot(const void* a, const void* b, const float* bias, float* out, int64_t M, int64_t d, int64_t lda, int64_t ldb,
+                           hipStream_t stream) {
+    SCONF_REQUIRE(d % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0, "sconf_rowdot: d, lda, ldb must be multiples of 8");
+    if (M == 0) return 0;
+    const unsigned g = (unsigned)std::min<long>(cdiv(M, 4), 65536);
+    hipLaunchKernelGGL(rowdot_kernel, dim3(g), dim3(256), 0, stream, (const bf16*)a, (const bf16*)b, bias, out, (long)M, (int)d, (long)lda, (long)ldb);
+    SCONF_LAUNCH_OK("sconf_rowdot");
+    return 0;
+}
+
 SCONF_API int sconf_colsum(const void* x, int x_dtype, float* out, int64_t M, int64_t N, int64_t ld, float alpha, hipStream_t stream);
 // floats of scratch sconf_softmax_bwd needs when it also produces the column sums of dx
 SCONF_API int64_t sconf_softmax_bwd_workspace(int64_t M, int64_t C) { return (int64_t)std::min<long>(M, SOFTMAX_BWD_SLABS) * C; }

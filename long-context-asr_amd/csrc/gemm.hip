@@ -297,7 +297,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ slab, float* __re
 
 // C ABI -----------------------------------------------------------------------------------------
 // layout: 0 = NT (A[M][K], B[N][K]); 1 = NN (A[M][K], B[K][N]); 2 = TN (A[K][M], B[K][N]).
-namespace { struct RotSpec { const float* cos = nullptr; const float* sin = nullptr; int n = 0, cols = 0; }; thread_local RotSpec g_rot; }
+namespace { struct RotSpec { const float* cos = nullptr; const float* sin = nullptr; int n = 0, cols = 0; }; thread_local RotSpec g_rot;
+            struct SmbSpec { const float* rowv = nullptr; float* colslab = nullptr; }; thread_local SmbSpec g_smb; }
 
 // Replaces: F.linear / fused_dense_cuda.linear_act_forward (fused_dense.py:277-279,329-332),
 // bias_act_linear_dgrad_bgrad (:354-356), linear_bias_wgrad (:113-115,338-340,375-378).
@@ -324,7 +325,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     SCONF_REQUIRE(split_k == 1 || out_f32, "sconf_gemm_bf16: split-K writes f32 partial slabs and needs out_f32");
     if (act == SCONF_ACT_DGELU || act == SCONF_ACT_DSILU || act == SCONF_ACT_MULAUX) SCONF_REQUIRE(aux != nullptr, "sconf_gemm_bf16: aux epilogue needs aux");
     if (act == SCONF_ACT_GELU_DSAVE) SCONF_REQUIRE(pre != nullptr, "sconf_gemm_bf16: GELU_DSAVE needs the pre buffer");
-    SCONF_REQUIRE(act >= 0 && act <= 6, "sconf_gemm_bf16: bad act %d", act);
+    SCONF_REQUIRE(act >= 0 && (act <= 6 || (act == SCONF_ACT_SMAXBWD && g_smb.rowv)), "sconf_gemm_bf16: bad act %d", act);
 
     GemmParams p;
     p.A = (const bf16*)A; p.B = (const bf16*)B; p.C = C;
@@ -338,6 +339,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
 #endif
     { const char* e = getenv("SCONF_GEMM_GM"); p.gm = e ? atoi(e) : 0; }                  // tuning: L2 patch height of the 256-row kernels
     p.rot_cos = g_rot.cos; p.rot_sin = g_rot.sin; p.rot_n = g_rot.n; p.rot_cols = g_rot.cols;   // set only inside sconf_gemm_qkv_rotary
+    p.rowv = g_smb.rowv; p.colslab = g_smb.colslab;                                              // set only inside sconf_gemm_softmax_bwd
     const int nkt = cdiv(K, BK);
     p.k_per_split = cdiv(nkt, split_k) * BK;
     const int splits = cdiv(K, p.k_per_split);
@@ -345,7 +347,7 @@ SCONF_API int sconf_gemm_bf16(int layout, const void* A, const void* B, void* C,
     p.split_stride = splits > 1 ? M * ldc : 0;
     if (splits > 1) SCONF_REQUIRE(!bias && !resid && act == SCONF_ACT_NONE && !pre, "sconf_gemm_bf16: split-K supports only the plain epilogue");
 
-    if (p.rot_cos) {                                   // only the 256-wide NT kernel has the rotary epilogue: the caller falls back otherwise
+    if (p.rot_cos || act == SCONF_ACT_SMAXBWD) {      // only the 256-row NT kernels have these epilogues: the caller falls back otherwise
         if (getenv("SCONF_GEMM_NO_256") || !sconf_gemm256_eligible(p, layout)) return 2;
         return sconf_gemm256_launch(p, layout, stream);
     }
@@ -406,6 +408,21 @@ SCONF_API int sconf_gemm_qkv_rotary(const void* A, const void* W, void* C, int64
     rc = sconf_gemm_bf16(0, A, W, C, M, N, K, lda, ldb, N, bias, nullptr, 0, nullptr, 0, nullptr, 0, 1.f, SCONF_ACT_NONE, 0, 1, stream);
     if (rc) return rc;
     return sconf_rotary_inplace(C, cos_tab, sin_tab, M / seq_len, seq_len, H, D, stream);
+}
+
+// Softmax backward inside the GEMM that produces its input gradient (the self-conditioning reprojection's dgrad, sconformer_xl.py:241-243
+// backward): dl[m][v] = probs[m][v] * ((dy Wt^T)[m][v] - delta[m]) in bf16, where delta[m] = sum_v probs dp is handed in (it equals
+// sum_c dy[m][c] * (reprojection output before bias / residual)[m][c]: sconf_rowdot on the forward's saved product) - dp = dy Wt^T is
+// never written.  colslab (2 * M / 256, V) f32 receives per-(row panel, wave row) column sums of dl (the decoder bias gradient: add
+// them up with sconf_colsum).  Returns 2 when the shape does not take the 256-row NT kernel (the caller then runs the plain GEMM +
+// sconf_softmax_bwd); otherwise 0 / an error.
+SCONF_API int sconf_gemm_softmax_bwd(const void* dy, const void* Wt, const void* probs, const float* delta, void* dl, float* colslab,
+                                     int64_t M, int64_t V, int64_t K, int64_t lddy, int64_t ldw, int64_t ldp, hipStream_t stream) {
+    SCONF_REQUIRE(delta && colslab && probs, "sconf_gemm_softmax_bwd: delta, colslab and probs are required");
+    g_smb.rowv = delta; g_smb.colslab = colslab;
+    const int rc = sconf_gemm_bf16(0, dy, Wt, dl, M, V, K, lddy, ldw, V, nullptr, nullptr, 0, probs, ldp, nullptr, 0, 1.f, SCONF_ACT_SMAXBWD, 0, 1, stream);
+    g_smb = SmbSpec();
+    return rc;
 }
 
 // Which kernel sconf_gemm_bf16 runs for a problem (diagnostics / benchmark bookkeeping; same decision code as the launch):

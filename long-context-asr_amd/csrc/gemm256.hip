@@ -191,7 +191,8 @@ template <> struct RawBf<4> { typedef bf16x4 type; };
 template <int ACT, bool RES, bool KS, int JH, int FL = -1, bool ROT = false>
 __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[2][4][2 + JH], const Item& it, int wr, int wc, int lane) {
     constexpr int WC = 32 + 16 * JH, WH = 4 * JH;
-    constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX;
+    constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX || ACT == SCONF_ACT_SMAXBWD;
+    constexpr bool SMB = ACT == SCONF_ACT_SMAXBWD;    // softmax backward: per-row scalar in, column sums out
     const int g = lane >> 4, mbase = it.m0 + 64 * wr + (lane & 15);
     if constexpr (ROT) {
         // qkv projection with the rotary rotation: with the rot row permutation (DmaOffs::set) the lane's lo run is (head, d0 .. d0 + 7)
@@ -241,17 +242,26 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
         for (int e = 0; e < WH; ++e) bhi[e] = 0.f;
         if (FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr) { loadv<8>(p.bias + nlo, blo); loadv<WH>(p.bias + nhi, bhi); }
         const long crow0 = (long)mbase * p.ldc, prow0 = (long)mbase * p.ldpre;      // per-lane row offsets; the rest is wave-uniform
-        if constexpr (FL >= 0 && (RES || ACT == SCONF_ACT_MULAUX)) {
+        if constexpr (FL >= 0 && (RES || ACT == SCONF_ACT_MULAUX || SMB)) {
             // Software-pipelined over the 8 row blocks: residual / aux loads are issued blocks ahead of the math and stores that
             // use them, so by the time they are needed the stores they queue behind have long drained.  (Loading each pair of blocks right after the previous pair's stores made every pair wait for a full
             // store round trip: 38-41 k cycles for an f32 + residual tile against ~8 k for a bf16 one.)
             constexpr int NB = 8;                             // row blocks
             constexpr int NS = RES ? (JH == 2 ? 2 : 3) : 5;   // register slots for blocks in flight (f32 residual: 16 VGPRs per block, aux: 8)
+            constexpr bool FIXED = RES;                      // fixed look-ahead of NS - 1 blocks
             float rl[NS][8], rh[NS][WH];
             typename RawBf<8>::type xl[NS];
             typename RawBf<WH>::type xh[NS];
+            float rowv[NS], cslo[8], cshi[WH];
+            if constexpr (SMB) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cslo[e] = 0.f;
+#pragma unroll
+                for (int e = 0; e < WH; ++e) cshi[e] = 0.f;
+            }
             auto fetch = [&](int rb, int slot) {
                 const int row = mbase + 128 * (rb >> 2) + 16 * (rb & 3);
+                if constexpr (SMB) rowv[slot] = p.rowv[row];
                 if constexpr (RES) { const float* q = p.resid + (long)row * p.ldr; loadv<8>(q + nlo, rl[slot]); loadv<WH>(q + nhi, rh[slot]); }
                 if constexpr (AUX) {
                     const bf16* q = p.aux + (long)row * p.ldaux;
@@ -260,7 +270,7 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
                 }
             };
 #pragma unroll
-            for (int nb = 0; nb < (RES ? NS - 1 : 1); ++nb) fetch(nb, nb);
+            for (int nb = 0; nb < (FIXED ? NS - 1 : 1); ++nb) fetch(nb, nb);
             // Aux tiles (bf16, 8 VGPRs per block): the look-ahead GROWS - blocks 1 | 2,3 | 4,5 | 6,7 are requested before blocks
             // 0 | 1 | 2 | 3 are processed, so after the first two round trips every remaining load is already in flight (one block
             // ahead throughout left 8 exposed round trips: 25 k cycles for the aux tile of an FF dgrad item).
@@ -268,19 +278,44 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
             for (int rb = 0; rb < NB; ++rb) {
                 {
                     // residual (arch-VGPR bound): fixed look-ahead of NS - 1 blocks; aux only: the growing schedule
-                    const int lo_b = RES ? rb + NS - 1 : (rb == 0 ? 1 : 2 * rb), hi_b = RES ? rb + NS - 1 : 2 * rb + 1;
+                    const int lo_b = FIXED ? rb + NS - 1 : (rb == 0 ? 1 : 2 * rb), hi_b = FIXED ? rb + NS - 1 : 2 * rb + 1;
 #pragma unroll
                     for (int nb = lo_b; nb <= hi_b; ++nb) if (nb < NB) fetch(nb, nb % NS);
                 }
                 const int h = rb >> 2, i = rb & 3, sl = rb % NS;
                 float vlo[8], vhi[WH], alo[8], ahi[WH], zlo[8], zhi[WH];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)xl[sl][e] : 0.f; zlo[e] = RES ? rl[sl][e] : 0.f; }
+                for (int e = 0; e < 8; ++e) { vlo[e] = acc[h][i][e >> 2][e & 3]; alo[e] = AUX ? (float)xl[sl][e] : 0.f; zlo[e] = RES ? rl[sl][e] : (SMB ? rowv[sl] : 0.f); }
 #pragma unroll
-                for (int e = 0; e < WH; ++e) { vhi[e] = acc[h][i][2 + (e >> 2)][e & 3]; ahi[e] = AUX ? (float)xh[sl][e] : 0.f; zhi[e] = RES ? rh[sl][e] : 0.f; }
+                for (int e = 0; e < WH; ++e) { vhi[e] = acc[h][i][2 + (e >> 2)][e & 3]; ahi[e] = AUX ? (float)xh[sl][e] : 0.f; zhi[e] = RES ? rh[sl][e] : (SMB ? rowv[sl] : 0.f); }
                 const long crow = crow0 + (long)(128 * h + 16 * i) * p.ldc, prow = prow0 + (long)(128 * h + 16 * i) * p.ldpre;
                 epi_math_store_at<8, ACT, FL>(p, vlo, blo, alo, zlo, crow + nlo, prow + nlo, it.split);
                 epi_math_store_at<WH, ACT, FL>(p, vhi, bhi, ahi, zhi, crow + nhi, prow + nhi, it.split);
+                if constexpr (SMB) {                           // (epi_math_store_at leaves the stored values in vlo / vhi)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) cslo[e] += vlo[e];
+#pragma unroll
+                    for (int e = 0; e < WH; ++e) cshi[e] += vhi[e];
+                }
+            }
+            if constexpr (SMB) {
+                // column sums of the wave's 128 rows: the 16 lanes of a DPP row hold 16 different rows of the same columns - butterfly
+                // (quad swaps, half-row mirror, row mirror), then lane 0 of each row stores its 8 + WH sums to the wave row's slab line
+                auto row_sum = [](float v) {
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));
+                    return v;
+                };
+#pragma unroll
+                for (int e = 0; e < 8; ++e) cslo[e] = row_sum(cslo[e]);
+#pragma unroll
+                for (int e = 0; e < WH; ++e) cshi[e] = row_sum(cshi[e]);
+                if ((lane & 15) == 0) {
+                    float* q = p.colslab + (long)(2 * (it.m0 / TM) + wr) * p.N;
+                    storev<8>(q + nlo, cslo); storev<WH>(q + nhi, cshi);
+                }
             }
             return;
         }
@@ -351,11 +386,16 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
 // `kind` is computed once per launch (wave-uniform), everything else takes the runtime-flag path.
 //   0 bf16 plain   1 bf16 + bias   2 f32 + residual   3 f32 + residual + bias   4 gelu' save (no bias)   5 * aux   6 generic
 //   7 bf16 + rotary   8 bf16 + bias + rotary   (256-wide tile only)
-__device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
+//   9 f32 + residual + bias, acc + bias also saved in bf16 (the self-conditioning reprojection)   10 softmax backward: (acc - rowv) * aux + column sums
+//   - these two live in kernel instantiations of their own (template parameter EK): in the common kernels their register needs made
+//     hipcc spill loop-carried values around EVERY item's epilogue (18 VGPRs to scratch, reloaded behind a vmcnt(0))
+__host__ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
     if (p.rot_cos) return p.bias ? 8 : 7;                        // (the launcher has checked everything else)
     const bool b = p.bias != nullptr, unit = p.alpha == 1.f;   // kinds 0, 1, 4 skip the alpha * v + residual step (the FF dgrad, kind 5, carries the branch scale in alpha)
     if (p.act == SCONF_ACT_GELU_DSAVE) return (!b && !p.out_f32 && !p.resid && unit) ? 4 : 6;
     if (p.act == SCONF_ACT_MULAUX) return (!b && !p.out_f32 && !p.resid && !p.pre) ? 5 : 6;
+    if (p.act == SCONF_ACT_SMAXBWD) return 10;                  // (the launcher has checked everything else)
+    if (p.act == SCONF_ACT_NONE && p.pre && p.out_f32 && p.resid && b) return 9;
     if (p.act != SCONF_ACT_NONE || p.pre) return 6;
     if (!p.out_f32 && !p.resid) return unit ? (b ? 1 : 0) : 6;
     if (p.out_f32 && p.resid) return b ? 3 : 2;
@@ -400,7 +440,7 @@ template <int JH> __device__ __forceinline__ void wait_window(bool streaming) {
     else VMCNT(7);
 }
 
-template <bool KS, int JH>
+template <bool KS, int JH, int EK = -1>
 __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
     constexpr int WC = 32 + 16 * JH, TN = 4 * WC;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A0 | A1 | B0 | B1], 128 KiB: the ONLY LDS object
@@ -610,6 +650,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #endif
         {
             if constexpr (KS) epilogue256<SCONF_ACT_NONE, false, true, JH>(p, acc, cit, wr, wc, lane);
+            else if constexpr (EK == 10) epilogue256<SCONF_ACT_SMAXBWD, false, false, JH, 4>(p, acc, cit, wr, wc, lane);
+            else if constexpr (EK == 9) epilogue256<SCONF_ACT_NONE, true, false, JH, 11>(p, acc, cit, wr, wc, lane);
             else EPILOGUE_NT(JH);
         }
 #pragma unroll
@@ -644,6 +686,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 // two phases after the read, as above.  RAW: 7 DMA instructions per wave and K-tile (2 + 2 + 2 + 1); the wait at the end of
 // a phase leaves the 7 youngest in flight, which retires A0/B0(s+2) at the end of P2(s+1) and A1/B1(s+2) at the end of
 // P0(s+2) - each one phase (and one barrier, two for the lagging wave row's partner) before its first read.
+template <int EK = -1>
 __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
     constexpr int JH = 1, WC = 48, TN = 192;
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][A0 | A1 | B0 | B1], the ONLY LDS object
@@ -756,7 +799,8 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
         if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
 #endif
         {
-            EPILOGUE_NT(JH);
+            if constexpr (EK == 9) epilogue256<SCONF_ACT_NONE, true, false, JH, 11>(p, acc, cit, wr, wc, lane);
+            else EPILOGUE_NT(JH);
         }
 #pragma unroll
         for (int h = 0; h < 2; ++h)
@@ -797,17 +841,20 @@ static int num_cus_cached() {
     return cus;
 }
 
+static int epilogue_kind_host(const GemmParams& p) { const int k = epilogue_kind(p); return (k == 9 || k == 10) ? k : -1; }
+
 bool sconf_gemm256_eligible(const GemmParams& p, int layout) {
     if (layout != 0 && layout != 2) return false;
     const bool ks = layout == 2;
     // specialised epilogues: NT {plain, +residual, GELU_DSAVE, MULAUX} (bias / pre-save / f32 output in any of them); TN plain
     if (ks ? (p.act != SCONF_ACT_NONE || p.resid || p.pre)
-           : !(p.act == SCONF_ACT_NONE || ((p.act == SCONF_ACT_GELU_DSAVE || p.act == SCONF_ACT_MULAUX) && !p.resid))) return false;
+           : !(p.act == SCONF_ACT_NONE || ((p.act == SCONF_ACT_GELU_DSAVE || p.act == SCONF_ACT_MULAUX) && !p.resid) ||
+               (p.act == SCONF_ACT_SMAXBWD && !p.resid && !p.bias && !p.out_f32 && !p.pre && p.splits == 1))) return false;
     // 32-bit per-lane source offsets relative to a half-tile base
     if ((ks ? 64 : 256) * p.lda * 2 >= (1L << 32) || (ks ? 64 : 256) * p.ldb * 2 >= (1L << 32)) return false;
     const int cus = num_cus_cached();
     const int w = pick_width(p, layout, cus);
-    if (!w) return false;
+    if (!w || (p.act == SCONF_ACT_SMAXBWD && w != 256)) return false;
     // one workgroup per CU: below ~3/4 of a round the 128x128 kernel (2 per CU, 4x the tiles) fills the chip better
     return (long)(p.M / TM) * (p.N / w) * p.splits * 4 >= 3L * cus;
 }
@@ -821,17 +868,24 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm192_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm192_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm192_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
     const int cus = num_cus_cached();
     const int w = pick_width(p, layout, cus);
     const int total = (p.M / TM) * (p.N / w) * p.splits;
     dim3 grid(std::min(total, cus)), block(512);
+    const int ek = layout == 2 ? -1 : epilogue_kind_host(p);
     if (layout == 2)   hipLaunchKernelGGL((gemm256_kernel<true, 2>), grid, block, shmem, stream, p);
+    else if (ek == 10) hipLaunchKernelGGL((gemm256_kernel<false, 2, 10>), grid, block, shmem, stream, p);      // (w == 256: sconf_gemm256_eligible)
+    else if (w == 256 && ek == 9) hipLaunchKernelGGL((gemm256_kernel<false, 2, 9>), grid, block, shmem, stream, p);
     else if (w == 256) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, shmem, stream, p);
     else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
-    else               hipLaunchKernelGGL(gemm192_kernel, grid, block, shmem, stream, p);
+    else if (ek == 9)  hipLaunchKernelGGL(gemm192_kernel<9>, grid, block, shmem, stream, p);
+    else               hipLaunchKernelGGL(gemm192_kernel<-1>, grid, block, shmem, stream, p);
     SCONF_LAUNCH_OK("sconf_gemm_bf16 (256-row tile)");
 #ifdef SCONF_GEMM_STAMP
     if (getenv("SCONF_GEMM_STAMP_PRINT") && (layout == 2 || w == 256)) {

@@ -23,6 +23,9 @@ struct GemmParams {
     // NeoX rotary fused into the epilogue of the qkv projection (sconf_gemm_qkv_rotary; 256x256 NT kernel, head_dim 128): output
     // columns < rot_cols are (head, d) with d < 128; row r is position r % rot_n; tables (rot_n, 64) f32.  null = no rotation.
     const float* rot_cos; const float* rot_sin; int rot_n, rot_cols;
+    // softmax backward in the epilogue (sconf_gemm_softmax_bwd; 256-row NT kernel): out = (acc - rowv[m]) * aux[m][n], and the column
+    // sums of the output of every (256-row item, wave row) go to colslab[2 * m0 / 256 + wave row][N] (f32; the bias gradient).
+    const float* rowv; float* colslab;
 #ifdef SCONF_GEMM_PROBE
     int debug;                                      // probe builds only (make PROBE=1; SCONF_GEMM_DEBUG): 1 = skip epilogue stores, 2 = skip the epilogue
     long long* stamps;                              // probe: per workgroup [64 items][4] {realtime at epilogue start, cycles at start, at end, after the next item's first wait}
@@ -48,7 +51,7 @@ template <int W> __device__ __forceinline__ void storev(float* p, const float (&
 
 template <int W> struct EpiIn { float ax[W], rs[W]; };
 __device__ __forceinline__ bool epi_uses_aux(const GemmParams& p) {
-    return p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX;
+    return p.act == SCONF_ACT_DGELU || p.act == SCONF_ACT_DSILU || p.act == SCONF_ACT_MULAUX || p.act == SCONF_ACT_SMAXBWD;
 }
 template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, EpiIn<W>& in, int m, int n) {
 #pragma unroll
@@ -61,8 +64,8 @@ template <int W> __device__ __forceinline__ void epi_load(const GemmParams& p, E
 // bias, aux and residual values (zeros where absent), loaded by the caller - ahead of any store where it matters: on gfx950
 // loads and stores retire through one in-order counter, so a load issued behind a store waits for that store's completion.
 // FL >= 0 also fixes, at compile time, whether a bias is added (bit 0), whether the output is f32 (bit 1) and whether the final
-// alpha * v + residual step is the identity (bit 2: alpha == 1, no residual), and promises that
-// p.pre is only used by GELU_DSAVE: with those known the compiler emits no branch and - the point - no conservative
+// alpha * v + residual step is the identity (bit 2: alpha == 1, no residual), whether acc + bias is saved to p.pre (bit 3), and
+// promises that p.pre is otherwise only used by GELU_DSAVE: with those known the compiler emits no branch and - the point - no conservative
 // `s_waitcnt vmcnt(0)` in front of each bias use (which drained the stores of the previous row every time).  coff / poff are
 // the element offsets of the run in C and in pre (row offset computed once per row block by the caller).
 template <int W, int ACT = -1, int FL = -1>
@@ -71,7 +74,7 @@ __device__ __forceinline__ void epi_math_store_at(const GemmParams& p, float (&v
     const int act = ACT >= 0 ? ACT : p.act;
     const bool has_bias = FL >= 0 ? (FL & 1) != 0 : p.bias != nullptr;
     const bool f32o = FL >= 0 ? (FL & 2) != 0 : p.out_f32 != 0;
-    const bool has_pre = FL >= 0 ? false : p.pre != nullptr;
+    const bool has_pre = FL >= 0 ? (FL & 8) != 0 : p.pre != nullptr;
     if (has_bias) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] += bs[e];
@@ -90,6 +93,9 @@ __device__ __forceinline__ void epi_math_store_at(const GemmParams& p, float (&v
     if (act == SCONF_ACT_MULAUX) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] *= ax[e];
+    } else if (act == SCONF_ACT_SMAXBWD) {          // rs carries the row's scalar (the caller sets FL bit 2: no alpha / residual step)
+#pragma unroll
+        for (int e = 0; e < W; ++e) v[e] = (v[e] - rs[e]) * ax[e];
     } else if (act == SCONF_ACT_GELU) {
 #pragma unroll
         for (int e = 0; e < W; ++e) v[e] = geluf_(v[e]);

@@ -508,6 +508,12 @@ def conv_block(x, nw, nb, wpw1, bpw1, wdw, bdw, brn_w, brn_b, running_mean, runn
 # =================================================================================================
 # self-conditioning: x + reprojection(softmax(ff(norm(x))))  — sconformer_xl.py:241-243, decoder.py:6-32
 # =================================================================================================
+def sc_delta_enabled(M: int, V: int, d: int) -> bool:
+    """Self-conditioning backward with the softmax backward inside the reprojection's dgrad GEMM (SCONF_SC_DELTA=0: the separate
+    GEMM + softmax_bwd passes): needs a shape the 256-row NT GEMM kernel takes (the paper configs; not the tiny test models)."""
+    return os.environ.get('SCONF_SC_DELTA', '1') != '0' and ops.gemm_softmax_bwd_eligible(M, V, d)
+
+
 class SelfCondFn(Function):
     @staticmethod
     def forward(ctx, x, hn_pre, nw, nb, wff, bff, wre, bre, has_norm: bool, mode: str, eps: float):
@@ -522,8 +528,15 @@ class SelfCondFn(Function):
         wfh, wrh = wcast(wff), wcast(wre)
         logits = ops.gemm(hn, wfh, 'nt', bias=bff)                                    # (M, V+1) bf16
         p = ops.softmax_fwd(logits, False, BF16)
-        y = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32)
-        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wff), wcast_t(wre), bff, bre, hn, p)
+        # Backward without the (M, V+1) gradient of the probabilities (sc_delta): the softmax backward needs delta = sum_v p dp with
+        # dp = dy Wr; that is sum_c dy[c] r[c] with r = p Wr^T, the product of THIS GEMM - kept in bf16 (acc + bias, 2 B per element of
+        # (M, d)) so that the backward's dgrad GEMM can apply p * (dp - delta) in its epilogue and never write dp.
+        delta_path = sc_delta_enabled(p.shape[0], p.shape[1], x.shape[1])
+        if delta_path:
+            y, r16 = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32, save_pre=True)
+        else:
+            y, r16 = ops.gemm(p, wrh, 'nt', bias=bre, resid=x, out_dtype=F32), None
+        ctx.save_for_backward(x, nw, nb, mean, rstd, wcast_t(wff), wcast_t(wre), bff, bre, hn, p, r16)
         ctx.cfg = (has_norm, mode, eps, hn_pre is not None)
         ctx.P = (nw, nb, wff, bff, wre, bre)
         return y
@@ -532,14 +545,18 @@ class SelfCondFn(Function):
     def backward(ctx, dy):
         has_norm, mode, eps, pre = ctx.cfg
         pnw, pnb, pwf, pbf, pwr, pbr = ctx.P
-        x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p = ctx.saved_tensors
+        x, nw, nb, mean, rstd, wft, wrt, bff, bre, hn, p, r16 = ctx.saved_tensors
         dy = dy.contiguous()
         dy16, dycs = _take_twin(dy)
-        dp = ops.gemm(dy16, wrt, 'nt')                                                # (M, V+1)
         dwr = _wgrad(dy16, p, pwr)
         dbr = _bgrad(dy16, pbr, colsum=dycs)
         gbf = _G(pbf)                                                                  # bias gradient = column sums of dl, same pass
-        dl = ops.softmax_bwd(p, dp, False, BF16, colsum_into=gbf.t)
+        if r16 is not None:
+            delta = ops.rowdot(dy16, r16, bre)                                         # (M,) = sum_v p * (dy Wr)
+            dl = ops.gemm_softmax_bwd(dy16, wrt, p, delta, colsum_into=gbf.t)          # p * (dy Wr - delta), bf16
+        else:
+            dp = ops.gemm(dy16, wrt, 'nt')                                             # (M, V+1)
+            dl = ops.softmax_bwd(p, dp, False, BF16, colsum_into=gbf.t)
         dwf = _wgrad(dl, hn, pwf)
         dbf = gbf.out()
         dhn = ops.gemm(dl, wft, 'nt')

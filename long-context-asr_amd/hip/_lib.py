@@ -17,6 +17,8 @@ vp, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
 PROTOTYPES = {
     'sconf_gemm_bf16': [i32, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, i64, vp, i64, vp, i64, f32, i32, i32, i32, vp],
     'sconf_gemm_qkv_rotary': [vp, vp, vp, i64, i64, i64, i64, i64, i64, vp, vp, vp, i64, vp],
+    'sconf_gemm_softmax_bwd': [vp, vp, vp, vp, vp, vp, i64, i64, i64, i64, i64, i64, vp],
+    'sconf_rowdot': [vp, vp, vp, vp, i64, i64, i64, i64, vp],
     'sconf_gemm_num_splits': [i64, i32],
     'sconf_splitk_reduce': [vp, vp, i64, i64, i32, vp],
     'sconf_norm_fwd': [i32, vp, i32, vp, vp, vp, i32, vp, vp, i64, i64, f32, vp],

@@ -304,6 +304,40 @@ def softmax_bwd(y: torch.Tensor, dy: torch.Tensor, log: bool, out_dtype: torch.d
     return dx
 
 
+def rowdot(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[m] = sum_c a[m, c] * (b[m, c] - bias[c])  (a, b bf16 (M, d); bias f32 (d) or None) -> (M,) f32."""
+    _chk(a, 'a', torch.bfloat16); _chk(b, 'b', torch.bfloat16)
+    if a.shape != b.shape or a.dim() != 2: raise ValueError('rowdot: a and b must be (M, d) of one shape')
+    if bias is not None: _chk(bias, 'bias', torch.float32)
+    M, d = a.shape
+    out = torch.empty(M, dtype=torch.float32, device=a.device)
+    _lib.call('sconf_rowdot', _p(a), _p(b), _p(bias), _p(out), M, d, a.stride(0), b.stride(0), _stream())
+    return out
+
+
+def gemm_softmax_bwd_eligible(M: int, V: int, K: int) -> bool:
+    """Whether gemm_softmax_bwd has a kernel for (M, K) x (V, K)^T (the 256-row NT kernels; same decision code as the launch)."""
+    return int(_lib.load().sconf_gemm_variant(0, M, V, K, K, K, 1, 7, 0, 0)) in (1, 2)
+
+
+def gemm_softmax_bwd(dy: torch.Tensor, wt: torch.Tensor, probs: torch.Tensor, delta: torch.Tensor,
+                     colsum_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dl = probs * (dy @ wt.T - delta[:, None]) in bf16 without writing dy @ wt.T (softmax backward in the GEMM epilogue);
+    colsum_into (f32, V) += column sums of dl.  dy (M, K), wt (V, K), probs (M, V) bf16; delta (M,) f32 = sum_v probs * (dy @ wt.T)."""
+    _chk(dy, 'dy', torch.bfloat16); _chk(wt, 'wt', torch.bfloat16); _chk(probs, 'probs', torch.bfloat16); _chk(delta, 'delta', torch.float32)
+    M, K = dy.shape; V = wt.shape[0]
+    if tuple(probs.shape) != (M, V) or wt.shape[1] != K or delta.numel() != M: raise ValueError('gemm_softmax_bwd: shapes')
+    if not gemm_softmax_bwd_eligible(M, V, K): raise ValueError(f'gemm_softmax_bwd: no kernel for {M} x {V} x {K} (check gemm_softmax_bwd_eligible)')
+    dl = torch.empty(M, V, dtype=torch.bfloat16, device=dy.device)
+    slab = torch.empty(2 * (M // 256), V, dtype=torch.float32, device=dy.device)
+    _lib.call('sconf_gemm_softmax_bwd', _p(dy), _p(wt), _p(probs), _p(delta), _p(dl), _p(slab), M, V, K, dy.stride(0), wt.stride(0),
+              probs.stride(0), _stream())
+    if colsum_into is not None:
+        _chk(colsum_into, 'colsum_into', torch.float32)
+        colsum_(slab, colsum_into)
+    return dl
+
+
 def colsum_(x: torch.Tensor, out: torch.Tensor, alpha: float = 1.0) -> torch.Tensor:
     """out[n] += alpha * sum_m x[m, n]  (in place, f32)."""
     _chk(x, 'x'); _chk(out, 'out', torch.float32)

@@ -204,6 +204,23 @@ def softmax_bwd(y, dy, log, out_dtype, colsum_into=None):
     return dx
 
 
+def rowdot(a, b, bias=None):
+    bf = b.to(f32) if bias is None else b.to(f32) - bias
+    return (a.to(f32) * bf).sum(-1)
+
+
+def gemm_softmax_bwd_eligible(M, V, K):
+    """Shape rule of the 256-row NT kernels (whole 256 x 256 tiles, whole K-tiles, at least 3/4 of a round of 256 workgroups)."""
+    return M % 256 == 0 and V % 256 == 0 and K % 64 == 0 and (M // 256) * (V // 256) * 4 >= 3 * 256
+
+
+def gemm_softmax_bwd(dy, wt, probs, delta, colsum_into=None):
+    dp = dy.to(f32) @ wt.to(f32).t()
+    dl = (probs.to(f32) * (dp - delta[:, None])).to(torch.bfloat16)
+    if colsum_into is not None: colsum_into += dl.to(f32).sum(0)
+    return dl
+
+
 def colsum_(x, out, alpha=1.0):
     out += alpha * x.to(f32).reshape(-1, x.shape[-1]).sum(0)
     return out

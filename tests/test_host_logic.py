@@ -128,6 +128,41 @@ def test_module_level_branches_and_logits(emulated_ops):
     assert float((torch.log_softmax(out_l, -1) - out_p).abs().max()) < 0.2    # BRN buffers moved between the two calls
 
 
+def test_self_conditioning_backward_through_the_saved_product(emulated_ops, monkeypatch):
+    """SelfCondFn's two backward forms - delta = sum_v p dp from the forward's saved reprojection product + softmax backward in the
+    dgrad GEMM's epilogue, and the plain GEMM + softmax_bwd (SCONF_SC_DELTA=0) - give the same gradients (host wiring; the kernels
+    are checked in test_kernels_gpu.py).  The emulated eligibility rule is relaxed so that a small shape takes the first form."""
+    import lcasr_amd.functional as Fn
+    monkeypatch.setattr(emulated_ops, 'gemm_softmax_bwd_eligible', lambda M, V, K: True)
+    g = torch.Generator().manual_seed(5)
+    M, d, V = 48, 64, 32
+    mk = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).requires_grad_(True)
+    x, nw, nb = mk(M, d), mk(d, sc=0.3), mk(d, sc=0.1)
+    wff, bff, wre, bre = mk(V, d, sc=0.2), mk(V, sc=0.1), mk(d, V, sc=0.2), mk(d, sc=0.1)
+    params = (x, nw, nb, wff, bff, wre, bre)
+    dy = torch.randn(M, d, generator=g)
+
+    def run(flag):
+        monkeypatch.setenv('SCONF_SC_DELTA', flag)
+        Fn.clear_weight_cache()
+        for t in params: t.grad = None
+        y = Fn.selfcond_block(x, nw, nb, wff, bff, wre, bre)
+        y.backward(dy)
+        return y.detach().clone(), [t.grad.clone() for t in params]
+
+    y1, g1 = run('1')
+    y0, g0 = run('0')
+    assert torch.equal(y1, y0)
+    for a, b, name in zip(g1, g0, 'x nw nb wff bff wre bre'.split()):
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) + 1e-6, name
+    f = lambda: torch.nn.functional.layer_norm(x, (d,), nw, nb)
+    ref = x + torch.softmax(f() @ wff.t() + bff, -1) @ wre.t() + bre        # sconformer_xl.py:241-243 in f32
+    for t in params: t.grad = None
+    ref.backward(dy)
+    for a, t, name in zip(g1, params, 'x nw nb wff bff wre bre'.split()):
+        assert float((a - t.grad).abs().max()) <= 5e-2 * float(t.grad.abs().max()) + 1e-6, name
+
+
 def test_param_groups_quirk():
     """base.py:42-45 sends blacklist modules to no_decay and the norms to decay (kept as in the reference)."""
     fx = load_golden('tiny_ln_equal')

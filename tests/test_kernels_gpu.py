@@ -124,7 +124,8 @@ def test_gemm_256_row_kernels_nt(ops, N, K, variant, monkeypatch):
     ref = a.float() @ b.float().t()
     cases = [dict(), dict(bias=bias), dict(bias=bias, act='gelu_dsave', save_pre=True), dict(aux=aux, act='mulaux', alpha=0.5),
              dict(bias=bias, resid=resid, alpha=0.5, out_dtype=F32), dict(out_dtype=F32), dict(bias=bias, save_pre=True),
-             dict(resid=resid, out_dtype=F32), dict(act='gelu_dsave', save_pre=True)]     # + the bias-free specialised epilogues
+             dict(resid=resid, out_dtype=F32), dict(act='gelu_dsave', save_pre=True),     # + the bias-free specialised epilogues
+             dict(bias=bias, resid=resid, out_dtype=F32, save_pre=True)]                  # + the reprojection's acc + bias save (own kernels)
     for kw in cases:
         new = ops.gemm(a, b, 'nt', **kw)
         monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
@@ -136,11 +137,40 @@ def test_gemm_256_row_kernels_nt(ops, N, K, variant, monkeypatch):
         if not kw:
             assert float((new[0].float() - ref).abs().max()) <= 8e-3 * float(ref.abs().max())
         if 'resid' in kw and 'bias' in kw:
-            exp = resid + 0.5 * (ref + bias)
+            exp = resid + kw.get('alpha', 1.0) * (ref + bias)
             assert float((new[0] - exp).abs().max()) <= 2e-3 * float(exp.abs().max())
     acc = torch.randn(M, N, generator=torch.Generator().manual_seed(1)).cuda(); acc0 = acc.clone()
     ops.gemm(a, b, 'nt', alpha=2.0, accum=acc)                        # C += alpha A.B in place (direct gradient accumulation)
     assert float((acc - (acc0 + 2.0 * ref)).abs().max()) <= 2e-3 * float(ref.abs().max()) * 2
+
+
+@pytest.mark.parametrize('V,K', [(1024, 768), (4096, 256)])
+def test_gemm_softmax_bwd_and_rowdot(ops, V, K):
+    """Backward of x + reprojection(softmax(logits)) without the gradient of the probabilities (sconformer_xl.py:241-243):
+    dl = p * (dy Wr - delta) from the GEMM's epilogue (+ its column sums), delta = sum_v p * (dy Wr) obtained as
+    rowdot(dy, r - bias) from the forward's saved product r = p Wr^T + bias.  References in f32."""
+    M = 16384
+    assert ops.gemm_softmax_bwd_eligible(M, V, K) and not ops.gemm_softmax_bwd_eligible(M - 8, V, K) and not ops.gemm_softmax_bwd_eligible(M, V + 16, K)
+    g = torch.Generator().manual_seed(V + K)
+    probs = torch.softmax(torch.randn(M, V, generator=g) * 2.0, -1).to(BF).cuda()
+    dy = (torch.randn(M, K, generator=g) * 0.5).to(BF).cuda()
+    wr = (torch.randn(K, V, generator=g) * 0.3).to(BF).cuda()           # reprojection weight (d, V); its transposed shadow is (V, d)
+    bias = torch.randn(K, generator=g).cuda()
+    wt = wr.t().contiguous()
+    dp = dy.float() @ wr.float()                                        # (M, V)
+    delta_ref = (probs.float() * dp).sum(-1)
+    r16 = (probs.float() @ wr.float().t() + bias).to(BF)               # what the forward GEMM saves (acc + bias in bf16)
+    delta = ops.rowdot(dy, r16, bias)
+    exact = (dy.float() * (r16.float() - bias)).sum(-1)
+    assert float((delta - exact).abs().max()) <= 1e-4 * float(exact.abs().max()) + 1e-5, 'rowdot vs the same sum in f32'
+    assert float((delta - delta_ref).abs().max()) <= 2e-2 * float(delta_ref.abs().max()), 'delta through the saved product vs sum_v p dp'
+    cs = torch.ones(V).cuda()
+    dl = ops.gemm_softmax_bwd(dy, wt, probs, delta_ref.contiguous(), colsum_into=cs)
+    ref = probs.float() * (dp - delta_ref[:, None])
+    close(dl, ref, name='dl = p (dp - delta)')
+    close(cs, 1.0 + dl.float().sum(0), name='column sums of dl', tol=2e-3)
+    old = ops.softmax_bwd(probs, ops.gemm(dy, wt, 'nt'), False, BF)     # the two-pass path rounds dp to bf16 first
+    assert float((dl.float() - old.float()).abs().max()) <= 2e-2 * float(ref.abs().max())
 
 
 @pytest.mark.parametrize('M,N,split', [(3072, 768, 7), (768, 768, 28), (2304, 1024, 7)])

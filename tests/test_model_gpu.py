@@ -638,13 +638,11 @@ def test_two_ranks_on_the_hip_path_match_single_process_sum_of_shards(tmp_path):
     m, V = build_from_fixture(fx, 'cuda'), int(fx['cfg.vocab_size'])
     opt = MADGRAD(m.parameters(), lr=3e-3)
     x, ln, tg, tl = global_batch(V)
-    ctc = CTCLoss(blank=V, reduction='sum')
     ref_losses = []
     for _ in range(3):
         step = []
         for sl in (slice(0, 2), slice(2, 4)):
-            o = m(x[sl].cuda(), length=ln[sl].cuda())
-            loss = ctc(o['final_posteriors'].transpose(0, 1), tg[sl].cuda(), o['length'], tl[sl].cuda())
+            loss = m(x[sl].cuda(), length=ln[sl].cuda(), ctc_targets=(tg[sl].cuda(), tl[sl].cuda()))['ctc_nll'].sum()   # Trainer.step's operator
             (loss / (256 * 4) * 100).backward()
             step.append(float(loss))
         opt.step(max_norm=0.8); opt.zero_grad()
@@ -655,6 +653,6 @@ def test_two_ranks_on_the_hip_path_match_single_process_sum_of_shards(tmp_path):
     d = (r0['data'] - opt.flat[0].data.cpu()).abs()
     scale = float(opt.flat[0].data.abs().max())
     print(f'[2 ranks, one GPU, gloo] max |param diff| {float(d.max()):.2e} (max |param| {scale:.2f}); exposed all-reduce wait {r0["wait_ms"]} ms/step')
-    assert float(d.max()) < 2e-4, float(d.max())                                # float-atomics order + fused-loss vs two-call dlogits
+    assert float(d.max()) < 1e-5, float(d.max())                                # float-atomics order in the per-channel reductions only (measured 1.5e-8)
     for i in (1, 2):
         assert ref_losses[i][0] == pytest.approx(r0['losses'][i], rel=2e-3) and ref_losses[i][1] == pytest.approx(r1['losses'][i], rel=2e-3)
