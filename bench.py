@@ -67,8 +67,9 @@ PEAK_BF16_DENSE = 2.5e15        # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 M
 PEAK_HBM = 8.0e12               # MI355X_MICROARCH.md: 8.0 TB/s HBM3E (spec; 6.3 TB/s is what a copy reaches)
 
 
-GEMM_KERNELS = {0: 'gemm_kernel<NT> (128x128 tile)', 1: 'gemm256_kernel<false, 2> (NT, 256x256 tile)',
-                2: 'gemm192_kernel (NT, 256x192 tile, 3 phases per K-tile)', 3: 'gemm256_kernel<true, 2> (TN, 256x256 tile)'}
+GEMM_KERNELS = {0: 'gemm_kernel<NT> (128x128 tile)',
+                1: 'gemm256_kernel<false, 2, *> (NT, 256x256 tile; one instantiation per epilogue kind - the family row of the profile)',
+                2: 'gemm192_kernel<*> (NT, 256x192 tile, 3 phases per K-tile)', 3: 'gemm256_kernel<true, 2> (TN, 256x256 tile)'}
 
 
 class GemmTimer:
@@ -117,6 +118,28 @@ class GemmTimer:
             timer.log.append((var, 2.0 * m * n * k, nbytes))
             return out
         ops.gemm = gemm
+        inner_sb = ops.gemm_softmax_bwd
+
+        def gemm_softmax_bwd(dy, wt, probs, delta, colsum_into=None):     # a 256x256 NT launch too (softmax backward in its epilogue)
+            if not (timer.enabled or timer.count_only): return inner_sb(dy, wt, probs, delta, colsum_into)
+            (m, k), n = dy.shape, wt.shape[0]
+            if timer.count_only:
+                timer.warm_flops[1] = timer.warm_flops.get(1, 0.0) + 2.0 * m * n * k
+                timer.calls += 1
+                return inner_sb(dy, wt, probs, delta, colsum_into)
+            if timer.only != 1 or timer.used + 2 > len(timer.pool): return inner_sb(dy, wt, probs, delta, colsum_into)
+            e0, e1 = timer.pool[timer.used], timer.pool[timer.used + 1]
+            timer.used += 2
+            slab = torch.empty(2 * (m // 256), n, dtype=torch.float32, device=dy.device)      # (the wrapper's own allocation, outside the events)
+            dl = torch.empty(m, n, dtype=torch.bfloat16, device=dy.device)
+            e0.record()
+            _lib.call('sconf_gemm_softmax_bwd', dy.data_ptr(), wt.data_ptr(), probs.data_ptr(), delta.data_ptr(), dl.data_ptr(), slab.data_ptr(),
+                      m, n, k, dy.stride(0), wt.stride(0), probs.stride(0), torch.cuda.current_stream().cuda_stream)
+            e1.record()
+            if colsum_into is not None: ops.colsum_(slab, colsum_into)
+            timer.log.append((1, 2.0 * m * n * k, 2.0 * (m * k + n * k) + 4.0 * m * n + 4.0 * m + 4.0 * slab.numel()))
+            return dl
+        ops.gemm_softmax_bwd = gemm_softmax_bwd
         # attention forward / backward and one HBM-bound kernel (the pre-norm forward), timed the same way: ~30 more event
         # pairs per step
         inner_af, inner_ab, inner_nf = ops.attn_fwd, ops.attn_bwd, ops.norm_fwd
@@ -194,7 +217,7 @@ class GemmTimer:
         try:
             tname = next(n for n in ('r03_hbm_traffic.json', 'r02_hbm_traffic.json') if os.path.exists(os.path.join(ROOT, 'profiles', n)))
             tj = json.load(open(os.path.join(ROOT, 'profiles', tname)))
-            key = GEMM_KERNELS.get(top, '').split(' (')[0]
+            key = GEMM_KERNELS.get(top, '').split(' (')[0]                      # family rows are written by tools/hbm_traffic.py
             if key in tj['kernels']:
                 traffic, src = tj['kernels'][key]['hbm_bytes_per_launch'], f'profiles/{tname} (PMC, same batch)'
         except Exception:

@@ -188,7 +188,7 @@ struct Cursor {
 template <int W> struct RawBf;
 template <> struct RawBf<8> { typedef bf16x8 type; };
 template <> struct RawBf<4> { typedef bf16x4 type; };
-template <int ACT, bool RES, bool KS, int JH, int FL = -1, bool ROT = false>
+template <int ACT, bool RES, bool KS, int JH, int FL = -1, bool ROT = false, int DEEP = 0>
 __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&acc)[2][4][2 + JH], const Item& it, int wr, int wc, int lane) {
     constexpr int WC = 32 + 16 * JH, WH = 4 * JH;
     constexpr bool AUX = ACT == SCONF_ACT_DGELU || ACT == SCONF_ACT_DSILU || ACT == SCONF_ACT_MULAUX || ACT == SCONF_ACT_SMAXBWD;
@@ -247,8 +247,10 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
             // use them, so by the time they are needed the stores they queue behind have long drained.  (Loading each pair of blocks right after the previous pair's stores made every pair wait for a full
             // store round trip: 38-41 k cycles for an f32 + residual tile against ~8 k for a bf16 one.)
             constexpr int NB = 8;                             // row blocks
-            constexpr int NS = RES ? (JH == 2 ? 2 : 3) : 5;   // register slots for blocks in flight (f32 residual: 16 VGPRs per block, aux: 8)
-            constexpr bool FIXED = RES;                      // fixed look-ahead of NS - 1 blocks
+            // register slots for blocks in flight (f32 residual: 16 VGPRs per block, aux: 8).  DEEP (the one-epilogue kernels, which have
+            // ~30 VGPRs to spare): all aux blocks / 3-4 residual blocks requested up front - one exposed round trip instead of two.
+            constexpr int NS = DEEP ? (RES ? (JH == 2 ? 4 : 5) : 8) : (RES ? (JH == 2 ? 2 : 3) : 5);
+            constexpr bool FIXED = RES || DEEP;              // fixed look-ahead of NS - 1 blocks
             float rl[NS][8], rh[NS][WH];
             typename RawBf<8>::type xl[NS];
             typename RawBf<WH>::type xh[NS];
@@ -417,6 +419,25 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
             else if (p.resid)                   epilogue256<SCONF_ACT_NONE, true, false, JH_>(p, acc, cit, wr, wc, lane);        \
             else                                epilogue256<SCONF_ACT_NONE, false, false, JH_>(p, acc, cit, wr, wc, lane);       \
     }
+
+// One kernel instantiation per specialised epilogue (template parameter EK = the kind): a kernel that holds ONE epilogue is allocated
+// for that epilogue alone (206-226 VGPRs, no SGPR spills, against 255 + 6 for the kernel that switches between all of them).
+#ifndef DEEPV
+#define DEEPV 1
+#endif
+#define EPILOGUE_ONE(EK_, JH_)                                                                                        \
+    do {                                                                                                              \
+        if constexpr (EK_ == 0) epilogue256<SCONF_ACT_NONE, false, false, JH_, 4>(p, acc, cit, wr, wc, lane);         \
+        else if constexpr (EK_ == 1) epilogue256<SCONF_ACT_NONE, false, false, JH_, 5>(p, acc, cit, wr, wc, lane);    \
+        else if constexpr (EK_ == 2) epilogue256<SCONF_ACT_NONE, true, false, JH_, 2, false, DEEPV>(p, acc, cit, wr, wc, lane);     \
+        else if constexpr (EK_ == 3) epilogue256<SCONF_ACT_NONE, true, false, JH_, 3, false, DEEPV>(p, acc, cit, wr, wc, lane);     \
+        else if constexpr (EK_ == 4) epilogue256<SCONF_ACT_GELU_DSAVE, false, false, JH_, 4>(p, acc, cit, wr, wc, lane); \
+        else if constexpr (EK_ == 5) epilogue256<SCONF_ACT_MULAUX, false, false, JH_, 0, false, DEEPV>(p, acc, cit, wr, wc, lane);  \
+        else if constexpr (EK_ == 7) epilogue256<SCONF_ACT_NONE, false, false, JH_, 0, true>(p, acc, cit, wr, wc, lane); \
+        else if constexpr (EK_ == 8) epilogue256<SCONF_ACT_NONE, false, false, JH_, 1, true>(p, acc, cit, wr, wc, lane); \
+        else if constexpr (EK_ == 9) epilogue256<SCONF_ACT_NONE, true, false, JH_, 11, false, DEEPV>(p, acc, cit, wr, wc, lane);    \
+        else epilogue256<SCONF_ACT_SMAXBWD, false, false, JH_, 4, false, DEEPV>(p, acc, cit, wr, wc, lane);                         \
+    } while (0)
 
 #define VMCNT(n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
 // In-kernel time stamps (cdna_hip_programming.md section 7), DIAGNOSTIC build only (make EXTRA=-DSCONF_GEMM_STAMP; tools/gemm_stamp.py):
@@ -650,8 +671,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const GemmParams p) {
 #endif
         {
             if constexpr (KS) epilogue256<SCONF_ACT_NONE, false, true, JH>(p, acc, cit, wr, wc, lane);
-            else if constexpr (EK == 10) epilogue256<SCONF_ACT_SMAXBWD, false, false, JH, 4>(p, acc, cit, wr, wc, lane);
-            else if constexpr (EK == 9) epilogue256<SCONF_ACT_NONE, true, false, JH, 11>(p, acc, cit, wr, wc, lane);
+            else if constexpr (EK >= 0) EPILOGUE_ONE(EK, JH);
             else EPILOGUE_NT(JH);
         }
 #pragma unroll
@@ -799,7 +819,7 @@ __global__ __launch_bounds__(512) void gemm192_kernel(const GemmParams p) {
         if (p.debug != 2 || acc[0][0][0][0] == 1.2345e-30f)
 #endif
         {
-            if constexpr (EK == 9) epilogue256<SCONF_ACT_NONE, true, false, JH, 11>(p, acc, cit, wr, wc, lane);
+            if constexpr (EK >= 0) EPILOGUE_ONE(EK, JH);
             else EPILOGUE_NT(JH);
         }
 #pragma unroll
@@ -841,8 +861,6 @@ static int num_cus_cached() {
     return cus;
 }
 
-static int epilogue_kind_host(const GemmParams& p) { const int k = epilogue_kind(p); return (k == 9 || k == 10) ? k : -1; }
-
 bool sconf_gemm256_eligible(const GemmParams& p, int layout) {
     if (layout != 0 && layout != 2) return false;
     const bool ks = layout == 2;
@@ -865,27 +883,43 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
     static bool attr_set = false;
     const size_t shmem = 2 * BUF;
     if (!attr_set) {
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm192_kernel<-1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm192_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-        (void)hipFuncSetAttribute((const void*)gemm256_kernel<false, 2, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        const void* fns[] = {(const void*)gemm256_kernel<false, 2>, (const void*)gemm256_kernel<false, 1>, (const void*)gemm256_kernel<true, 2>,
+                             (const void*)gemm256_kernel<false, 2, 0>, (const void*)gemm256_kernel<false, 2, 1>, (const void*)gemm256_kernel<false, 2, 2>,
+                             (const void*)gemm256_kernel<false, 2, 3>, (const void*)gemm256_kernel<false, 2, 4>, (const void*)gemm256_kernel<false, 2, 5>,
+                             (const void*)gemm256_kernel<false, 2, 7>, (const void*)gemm256_kernel<false, 2, 8>, (const void*)gemm256_kernel<false, 2, 9>,
+                             (const void*)gemm256_kernel<false, 2, 10>, (const void*)gemm192_kernel<-1>, (const void*)gemm192_kernel<0>,
+                             (const void*)gemm192_kernel<1>, (const void*)gemm192_kernel<2>, (const void*)gemm192_kernel<3>, (const void*)gemm192_kernel<4>,
+                             (const void*)gemm192_kernel<5>, (const void*)gemm192_kernel<9>};
+        for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
         attr_set = true;
     }
     const int cus = num_cus_cached();
     const int w = pick_width(p, layout, cus);
     const int total = (p.M / TM) * (p.N / w) * p.splits;
     dim3 grid(std::min(total, cus)), block(512);
-    const int ek = layout == 2 ? -1 : epilogue_kind_host(p);
+    // NT: one kernel instantiation per specialised epilogue kind (SCONF_GEMM_ONE_KERNEL: the kernel that switches, A/B; kinds 9 / 10
+    // exist only as instantiations)
+    int ek = layout == 2 ? -1 : epilogue_kind(p);
+    if (ek == 6 || (ek < 9 && getenv("SCONF_GEMM_ONE_KERNEL"))) ek = -1;
+#define L256(EK_) hipLaunchKernelGGL((gemm256_kernel<false, 2, EK_>), grid, block, shmem, stream, p)
+#define L192(EK_) hipLaunchKernelGGL(gemm192_kernel<EK_>, grid, block, shmem, stream, p)
     if (layout == 2)   hipLaunchKernelGGL((gemm256_kernel<true, 2>), grid, block, shmem, stream, p);
-    else if (ek == 10) hipLaunchKernelGGL((gemm256_kernel<false, 2, 10>), grid, block, shmem, stream, p);      // (w == 256: sconf_gemm256_eligible)
-    else if (w == 256 && ek == 9) hipLaunchKernelGGL((gemm256_kernel<false, 2, 9>), grid, block, shmem, stream, p);
-    else if (w == 256) hipLaunchKernelGGL((gemm256_kernel<false, 2>), grid, block, shmem, stream, p);
-    else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
-    else if (ek == 9)  hipLaunchKernelGGL(gemm192_kernel<9>, grid, block, shmem, stream, p);
-    else               hipLaunchKernelGGL(gemm192_kernel<-1>, grid, block, shmem, stream, p);
+    else if (w == 256) {
+        switch (ek) {
+            case 0: L256(0); break; case 1: L256(1); break; case 2: L256(2); break; case 3: L256(3); break; case 4: L256(4); break;
+            case 5: L256(5); break; case 7: L256(7); break; case 8: L256(8); break; case 9: L256(9); break; case 10: L256(10); break;
+            default: L256(-1);
+        }
+    } else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
+    else {
+        switch (ek) {
+            case 0: L192(0); break; case 1: L192(1); break; case 2: L192(2); break; case 3: L192(3); break; case 4: L192(4); break;
+            case 5: L192(5); break; case 9: L192(9); break;
+            default: L192(-1);
+        }
+    }
+#undef L256
+#undef L192
     SCONF_LAUNCH_OK("sconf_gemm_bf16 (256-row tile)");
 #ifdef SCONF_GEMM_STAMP
     if (getenv("SCONF_GEMM_STAMP_PRINT") && (layout == 2 || w == 256)) {
