@@ -389,7 +389,8 @@ __device__ __forceinline__ void epilogue256(const GemmParams& p, const f32x4 (&a
 //   0 bf16 plain   1 bf16 + bias   2 f32 + residual   3 f32 + residual + bias   4 gelu' save (no bias)   5 * aux   6 generic
 //   7 bf16 + rotary   8 bf16 + bias + rotary   (256-wide tile only)
 //   9 f32 + residual + bias, acc + bias also saved in bf16 (the self-conditioning reprojection)   10 softmax backward: (acc - rowv) * aux + column sums
-//   - these two live in kernel instantiations of their own (template parameter EK): in the common kernels their register needs made
+//   11 f32 plain   12 f32 + bias   (the head's logits, the subsampler's output projection)
+//   - 9 .. 12 live only in kernel instantiations of their own (template parameter EK): in the common kernels their register needs made
 //     hipcc spill loop-carried values around EVERY item's epilogue (18 VGPRs to scratch, reloaded behind a vmcnt(0))
 __host__ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
     if (p.rot_cos) return p.bias ? 8 : 7;                        // (the launcher has checked everything else)
@@ -401,6 +402,7 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
     if (p.act != SCONF_ACT_NONE || p.pre) return 6;
     if (!p.out_f32 && !p.resid) return unit ? (b ? 1 : 0) : 6;
     if (p.out_f32 && p.resid) return b ? 3 : 2;
+    if (p.out_f32 && unit) return b ? 12 : 11;
     return 6;
 }
 #define EPILOGUE_NT(JH_)                                                                                              \
@@ -436,6 +438,8 @@ __host__ __device__ __forceinline__ int epilogue_kind(const GemmParams& p) {
         else if constexpr (EK_ == 7) epilogue256<SCONF_ACT_NONE, false, false, JH_, 0, true>(p, acc, cit, wr, wc, lane); \
         else if constexpr (EK_ == 8) epilogue256<SCONF_ACT_NONE, false, false, JH_, 1, true>(p, acc, cit, wr, wc, lane); \
         else if constexpr (EK_ == 9) epilogue256<SCONF_ACT_NONE, true, false, JH_, 11, false, DEEPV>(p, acc, cit, wr, wc, lane);    \
+        else if constexpr (EK_ == 11) epilogue256<SCONF_ACT_NONE, false, false, JH_, 6>(p, acc, cit, wr, wc, lane);   \
+        else if constexpr (EK_ == 12) epilogue256<SCONF_ACT_NONE, false, false, JH_, 7>(p, acc, cit, wr, wc, lane);   \
         else epilogue256<SCONF_ACT_SMAXBWD, false, false, JH_, 4, false, DEEPV>(p, acc, cit, wr, wc, lane);                         \
     } while (0)
 
@@ -887,7 +891,8 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
                              (const void*)gemm256_kernel<false, 2, 0>, (const void*)gemm256_kernel<false, 2, 1>, (const void*)gemm256_kernel<false, 2, 2>,
                              (const void*)gemm256_kernel<false, 2, 3>, (const void*)gemm256_kernel<false, 2, 4>, (const void*)gemm256_kernel<false, 2, 5>,
                              (const void*)gemm256_kernel<false, 2, 7>, (const void*)gemm256_kernel<false, 2, 8>, (const void*)gemm256_kernel<false, 2, 9>,
-                             (const void*)gemm256_kernel<false, 2, 10>, (const void*)gemm192_kernel<-1>, (const void*)gemm192_kernel<0>,
+                             (const void*)gemm256_kernel<false, 2, 10>, (const void*)gemm256_kernel<false, 2, 11>, (const void*)gemm256_kernel<false, 2, 12>,
+                             (const void*)gemm192_kernel<11>, (const void*)gemm192_kernel<12>, (const void*)gemm192_kernel<-1>, (const void*)gemm192_kernel<0>,
                              (const void*)gemm192_kernel<1>, (const void*)gemm192_kernel<2>, (const void*)gemm192_kernel<3>, (const void*)gemm192_kernel<4>,
                              (const void*)gemm192_kernel<5>, (const void*)gemm192_kernel<9>};
         for (const void* f : fns) (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
@@ -901,6 +906,7 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
     // exist only as instantiations)
     int ek = layout == 2 ? -1 : epilogue_kind(p);
     if (ek == 6 || (ek < 9 && getenv("SCONF_GEMM_ONE_KERNEL"))) ek = -1;
+    if (ek >= 11 && getenv("SCONF_GEMM_ONE_KERNEL")) ek = -1;
 #define L256(EK_) hipLaunchKernelGGL((gemm256_kernel<false, 2, EK_>), grid, block, shmem, stream, p)
 #define L192(EK_) hipLaunchKernelGGL(gemm192_kernel<EK_>, grid, block, shmem, stream, p)
     if (layout == 2)   hipLaunchKernelGGL((gemm256_kernel<true, 2>), grid, block, shmem, stream, p);
@@ -908,13 +914,14 @@ int sconf_gemm256_launch(const GemmParams& p, int layout, hipStream_t stream) {
         switch (ek) {
             case 0: L256(0); break; case 1: L256(1); break; case 2: L256(2); break; case 3: L256(3); break; case 4: L256(4); break;
             case 5: L256(5); break; case 7: L256(7); break; case 8: L256(8); break; case 9: L256(9); break; case 10: L256(10); break;
+            case 11: L256(11); break; case 12: L256(12); break;
             default: L256(-1);
         }
     } else if (getenv("SCONF_GEMM_192_4PHASE")) hipLaunchKernelGGL((gemm256_kernel<false, 1>), grid, block, shmem, stream, p);   // A/B
     else {
         switch (ek) {
             case 0: L192(0); break; case 1: L192(1); break; case 2: L192(2); break; case 3: L192(3); break; case 4: L192(4); break;
-            case 5: L192(5); break; case 9: L192(9); break;
+            case 5: L192(5); break; case 9: L192(9); break; case 11: L192(11); break; case 12: L192(12); break;
             default: L192(-1);
         }
     }

@@ -125,7 +125,8 @@ def test_gemm_256_row_kernels_nt(ops, N, K, variant, monkeypatch):
     cases = [dict(), dict(bias=bias), dict(bias=bias, act='gelu_dsave', save_pre=True), dict(aux=aux, act='mulaux', alpha=0.5),
              dict(bias=bias, resid=resid, alpha=0.5, out_dtype=F32), dict(out_dtype=F32), dict(bias=bias, save_pre=True),
              dict(resid=resid, out_dtype=F32), dict(act='gelu_dsave', save_pre=True),     # + the bias-free specialised epilogues
-             dict(bias=bias, resid=resid, out_dtype=F32, save_pre=True)]                  # + the reprojection's acc + bias save (own kernels)
+             dict(bias=bias, resid=resid, out_dtype=F32, save_pre=True),                  # + the reprojection's acc + bias save (own kernels)
+             dict(bias=bias, out_dtype=F32)]                                              # + the head's f32 logits
     for kw in cases:
         new = ops.gemm(a, b, 'nt', **kw)
         monkeypatch.setenv('SCONF_GEMM_NO_256', '1')
