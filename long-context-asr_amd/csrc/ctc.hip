@@ -194,13 +194,18 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     if (tid == 0) lat[W + 2] = (LT)0;                    // virtual frame -1 (row 1): all mass in state 0, so frame 0 is the general step
     __syncthreads();
 
-    float pf[4][MAXS], nx[4][MAXS];
+    // Frames are prefetched in groups of G (2 * G * MAXS registers): 4 at a few states per thread, 1 for the long lattices, whose
+    // frames are slow enough to cover a load by themselves (with MAXS = 16 and groups of 4 the prefetch alone was 128 VGPRs of
+    // the 128 a 1024-thread workgroup has: the kernel lived in scratch - 282 ms at N = 16384, S = 4096).
+    constexpr int G = MAXS <= 4 ? 4 : (MAXS <= 8 ? 2 : 1);
+    constexpr int CH = MAXS < 4 ? MAXS : 4;              // recursions interleaved at a time (stage by stage)
+    float pf[G][MAXS], nx[G][MAXS];
     // Unconditional loads from clamped (always valid) addresses: a load inside a branch is waited for inside that branch (vmcnt(0),
     // in order behind every store in flight) - eight serial memory round trips per group instead of a prefetch.  What the clamped
     // loads bring for frames >= T or states >= L is never used.
-    auto load_group = [&](float (&dst)[4][MAXS], int i0) {
+    auto load_group = [&](float (&dst)[G][MAXS], int i0) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < G; ++j) {
             const int i = min(i0 + j, T - 1);
             const int t = is_beta ? T - 1 - i : i;
 #pragma unroll
@@ -213,26 +218,26 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     };
     load_group(pf, 0);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < G; ++j)
 #pragma unroll
         for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(pf[j][k], -1e30f);
     double A = 0.0;                                      // offset of the stored rows, log2 units
     CSTAMP_DECL
     const int w0 = wave * 64 * MAXS, w1 = w0 + 64 * MAXS - 1;   // the wave's range of states
-    for (int i0 = 0; i0 < T; i0 += 4) {
-        load_group(nx, i0 + 4);                          // prefetch the next 4 time steps
+    for (int i0 = 0; i0 < T; i0 += G) {
+        load_group(nx, i0 + G);                          // prefetch the next G time steps
         CSTAMP(4);
-        if (i0 > 0) {                                    // the offset follows the maximum of the row stored at frame i0 - 1: one LDS round trip
-            const float4* pm = reinterpret_cast<const float4*>(wm);
-            const float4 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
-            const float m = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
-                                  fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
-            if (m > -1e30f) A += (double)m;
-        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < G; ++j) {
             const int i = i0 + j;
             if (i < T) {                                  // uniform across the workgroup
+                if (i > 0 && (i & 3) == 0) {              // the offset follows the maximum of the row stored at frame i - 1: one LDS round trip
+                    const float4* pm = reinterpret_cast<const float4*>(wm);
+                    const float4 m0 = pm[0], m1 = pm[1], m2 = pm[2], m3 = pm[3];
+                    const float m = fmaxf(fmaxf(fmaxf(fmaxf(m0.x, m0.y), fmaxf(m0.z, m0.w)), fmaxf(fmaxf(m1.x, m1.y), fmaxf(m1.z, m1.w))),
+                                          fmaxf(fmaxf(fmaxf(m2.x, m2.y), fmaxf(m2.z, m2.w)), fmaxf(fmaxf(m3.x, m3.y), fmaxf(m3.z, m3.w))));
+                    if (m > -1e30f) A += (double)m;
+                }
                 const int t = is_beta ? T - 1 - i : i;
                 LT* cur = lat + (i & 1) * W + 2;
                 const LT* prev = lat + ((i & 1) ^ 1) * W + 2;
@@ -242,50 +247,53 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 float* orow = out + (long)t * Lmax;
                 if (w0 <= hi && w1 >= lo) {                           // wave-uniform
                     if (cnt > 0) {
-                        LT pv[MAXS + 2];
-#pragma unroll
-                        for (int q = 0; q < MAXS + 2; ++q) pv[q] = prev[sp0 - 2 + q];
-                        CSTAMP(0);
-                        // The MAXS recursions stage by stage (sched_barrier pins the order): every stage is MAXS independent
+                        // CH recursions at a time, stage by stage (sched_barrier pins the order): every stage is CH independent
                         // instructions, so a chain's latency (f64 max / differences, exponentials, logarithm) is covered by its siblings.
-                        LT c[MAXS], m[MAXS], base[MAXS];
-                        float e0[MAXS], e1[MAXS], e2[MAXS];
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) { c[k] = skip_ok[k] ? pv[k] : NEG; m[k] = max_lt(pv[k + 2], pv[k + 1]); }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int k0 = 0; k0 < MAXS; k0 += CH) {
+                            LT pv[CH + 2];
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) m[k] = max_lt(m[k], c[k]);
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int q = 0; q < CH + 2; ++q) pv[q] = prev[sp0 + k0 - 2 + q];
+                            if (k0 == 0) CSTAMP(0);
+                            LT c[CH], m[CH], base[CH];
+                            float e0[CH], e1[CH], e2[CH];
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) {
-                            e0[k] = (float)(pv[k + 2] - m[k]); e1[k] = (float)(pv[k + 1] - m[k]); e2[k] = (float)(c[k] - m[k]);
-                            base[k] = sizeof(LT) == 8 ? (LT)__builtin_fma((double)pf[j][k], LOG2E_D, (double)m[k]) : (LT)(m[k] + pf[j][k] * (float)LOG2E_D);
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) { c[k] = skip_ok[k0 + k] ? pv[k] : NEG; m[k] = max_lt(pv[k + 2], pv[k + 1]); }
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) { e0[k] = __builtin_amdgcn_exp2f(e0[k]); e1[k] = __builtin_amdgcn_exp2f(e1[k]); e2[k] = __builtin_amdgcn_exp2f(e2[k]); }
-                        __builtin_amdgcn_sched_barrier(0);
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) m[k] = max_lt(m[k], c[k]);
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) e0[k] = __builtin_amdgcn_logf(e0[k] + e1[k] + e2[k]);
-                        __builtin_amdgcn_sched_barrier(0);
-                        CSTAMP(1);
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) {
+                                e0[k] = (float)(pv[k + 2] - m[k]); e1[k] = (float)(pv[k + 1] - m[k]); e2[k] = (float)(c[k] - m[k]);
+                                base[k] = sizeof(LT) == 8 ? (LT)__builtin_fma((double)pf[j][k0 + k], LOG2E_D, (double)m[k]) : (LT)(m[k] + pf[j][k0 + k] * (float)LOG2E_D);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int k = 0; k < MAXS; ++k) {
-                            const LT v = base[k] + (LT)e0[k];
-                            if (k < cnt) cur[sp0 + k] = v;
-                            const float rel = (float)((double)v - A); // log2 units, relative to the frame's offset
-                            if (k < cnt) {
-                                orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = rel * (float)LN2_D;
-                                mine = fmaxf(mine, rel);
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) { e0[k] = __builtin_amdgcn_exp2f(e0[k]); e1[k] = __builtin_amdgcn_exp2f(e1[k]); e2[k] = __builtin_amdgcn_exp2f(e2[k]); }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) e0[k] = __builtin_amdgcn_logf(e0[k] + e1[k] + e2[k]);
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int k = 0; k < CH; ++k) if (k0 + k < MAXS) {
+                                const LT v = base[k] + (LT)e0[k];
+                                const float rel = (float)((double)v - A); // log2 units, relative to the frame's offset
+                                if (k0 + k < cnt) {
+                                    cur[sp0 + k0 + k] = v;
+                                    orow[is_beta ? L - 1 - sp0 - k0 - k : sp0 + k0 + k] = rel * (float)LN2_D;
+                                    mine = fmaxf(mine, rel);
+                                }
                             }
                         }
+                        CSTAMP(1);
                     }
                 } else {
 #pragma unroll
                     for (int k = 0; k < MAXS; ++k)
                         if (k < cnt) { cur[sp0 + k] = NEG; orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = -INFINITY; }
                 }
-                if (j == 3) {
+                if ((i & 3) == 3) {
                     mine = wave_max_dpp(mine);
                     if ((tid & 63) == 0) wm[wave] = mine;
                 }
@@ -295,7 +303,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < G; ++j)
 #pragma unroll
             for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(nx[j][k], -1e30f);            // an emission of -inf must stay finite in the recursion
         CSTAMP(5);
@@ -468,7 +476,7 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     int nt = Lmax <= 256 ? 256 : (Lmax <= 512 ? 512 : 1024);     // the serial step costs a barrier + the slowest thread: few states each
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
-    const int spt_pad = spt <= 1 ? 1 : spt <= 2 ? 2 : spt <= 4 ? 4 : spt <= 8 ? 8 : 16;     // MAXS of the instantiation taken below
+    const int spt_pad = spt <= 4 ? spt : spt <= 6 ? 6 : spt <= 8 ? 8 : spt <= 10 ? 10 : spt <= 12 ? 12 : 16;   // MAXS of the instantiation taken below
     const bool f64_state = ((size_t)2 * (Lmax + spt_pad + 2)) * 8 + 144 <= 160 * 1024;        // else f32 state (lattices of more than ~10200 states)
     const size_t sh = ((size_t)2 * (Lmax + spt_pad + 2)) * (f64_state ? 8 : 4) + 144;
     SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
@@ -477,7 +485,8 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
         hipLaunchKernelGGL((ctc_alphabeta_kernel<MS, LT>), dim3((unsigned)(2 * B)), dim3(nt), sh, stream, lpg, targets, input_lengths, \
                            target_lengths, alpha, beta, nll, offs, (int)B, (int)N, (int)C, (int)Smax, Lmax, blank); } while (0)
 #define L(MS) do { if (f64_state) L2(MS, double); else L2(MS, float); } while (0)
-    if (spt <= 1) L(1); else if (spt <= 2) L(2); else if (spt <= 4) L(4); else if (spt <= 8) L(8); else L(16);
+    switch (spt_pad) { case 1: L(1); break; case 2: L(2); break; case 3: L(3); break; case 4: L(4); break; case 6: L(6); break; case 8: L(8); break;
+                       case 10: L(10); break; case 12: L(12); break; default: L(16); }
 #undef L2
 #undef L
 #ifdef CTC_STAMP
