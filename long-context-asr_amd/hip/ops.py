@@ -87,7 +87,14 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
         out_dtype = torch.float32
     out_f32 = out_dtype == torch.float32
     splits = _lib.load().sconf_gemm_num_splits(K, int(split_k)) if split_k > 1 else 1
-    if splits > 1:                                                     # deterministic split-K: partial slabs + fixed-order reduce
+    one_slab = False
+    if accum is not None and splits == 1 and layout == 'tn':
+        # in-place accumulation is a residual epilogue, which only the 128x128 kernel has for K-strided operands: when the 256-row TN
+        # kernel would take the plain problem, write one slab and add it with the split-K reduce (config 5's weight gradients: 13 per step)
+        lib = _lib.load()
+        one_slab = (lib.sconf_gemm_variant(2, M, N, K, a.stride(0), b.stride(0), 1, 0, 0, 0) == 3 and
+                    lib.sconf_gemm_variant(2, M, N, K, a.stride(0), b.stride(0), 1, 0, 1, 0) != 3)
+    if splits > 1 or one_slab:                                         # deterministic split-K: partial slabs + fixed-order reduce
         c = torch.empty(splits, M, N, dtype=torch.float32, device=a.device)
     elif accum is not None:
         c = resid = accum                                              # out = accum + alpha * A·B, element-wise in place
@@ -103,7 +110,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, layout: str = 'nt', bias: Optional[to
         if tuple(aux.shape) != (M, N): raise ValueError('aux shape mismatch')
     _lib.call('sconf_gemm_bf16', LAYOUT[layout], _p(a), _p(b), _p(c), M, N, K, a.stride(0), b.stride(0), N,
               _p(bias), _p(resid), N, _p(aux), N, _p(pre), N, float(alpha), ACT[act], int(out_f32), int(split_k), _stream())
-    if splits > 1:
+    if splits > 1 or one_slab:
         out = accum if accum is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
         _lib.call('sconf_splitk_reduce', _p(c), _p(out), splits, M * N, int(accum is not None), _stream())
         c = out

@@ -194,6 +194,20 @@ def test_gemm_256_row_kernel_tn_split_k(ops, M, N, split, monkeypatch):
     assert float((acc - 1 - ref).abs().max()) <= 1e-4 * float(ref.abs().max())
 
 
+def test_gemm_tn_accumulate_through_the_256_row_kernel(ops):
+    """C += alpha A^T B with split_k = 1 at a shape the 256-row TN kernel takes (config 5's weight gradients): that kernel has no
+    residual epilogue, so ops.gemm writes one slab and adds it with the split-K reduce instead of falling to the 128x128 kernel."""
+    K, M, N = 4096, 4096, 4096
+    assert _variant(ops, 'tn', M, N, K) == 3 and _variant(ops, 'tn', M, N, K, resid=True) != 3
+    g = torch.Generator().manual_seed(7)
+    a = (torch.randn(K, M, generator=g) * 0.3).to(BF).cuda(); b = (torch.randn(K, N, generator=g) * 0.3).to(BF).cuda()
+    acc = torch.randn(M, N, generator=g).cuda(); acc0 = acc.clone()
+    out = ops.gemm(a, b, 'tn', alpha=0.5, out_dtype=F32, accum=acc)
+    assert out.data_ptr() == acc.data_ptr()
+    ref = acc0 + 0.5 * (a.float().t() @ b.float())
+    assert float((acc - ref).abs().max()) <= 2e-3 * float(ref.abs().max())
+
+
 def test_gemm_rejects_bad_shapes(ops):
     with pytest.raises(RuntimeError):
         ops.gemm(dev(rnd(16, 12)), dev(rnd(16, 12, seed=1)), 'nt')      # K % 8 != 0
