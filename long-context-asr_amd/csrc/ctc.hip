@@ -198,7 +198,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     // frames are slow enough to cover a load by themselves (with MAXS = 16 and groups of 4 the prefetch alone was 128 VGPRs of
     // the 128 a 1024-thread workgroup has: the kernel lived in scratch - 282 ms at N = 16384, S = 4096).
     constexpr int G = MAXS <= 4 ? 4 : (MAXS <= 8 ? 2 : 1);
-    constexpr int CH = MAXS < 4 ? MAXS : 4;              // recursions interleaved at a time (stage by stage)
+    constexpr int CH = MAXS <= 6 ? MAXS : (MAXS <= 12 ? MAXS / 2 : 4);   // recursions interleaved at a time (stage by stage)
     float pf[G][MAXS], nx[G][MAXS];
     // Unconditional loads from clamped (always valid) addresses: a load inside a branch is waited for inside that branch (vmcnt(0),
     // in order behind every store in flight) - eight serial memory round trips per group instead of a prefetch.  What the clamped
