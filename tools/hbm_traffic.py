@@ -35,8 +35,8 @@ def main(out, dfetch, dwrite, batch='128'):
         ks[k] = {'launches': n, 'fetch_size_kb': round(fk, 1), 'write_size_kb': round(wk, 1), 'fetch_correction': 1 if narrow else 2,
                  'hbm_bytes_per_launch': int((1 if narrow else 2) * fk * 1024 + wk * 1024)}
     # family rows (one instantiation per epilogue kind): launch-weighted mean over the members, under the name bench.py looks up
-    for fam, pat in (('gemm256_kernel<false, 2, *>', 'gemm256_kernelILb0ELi2ELi'), ('gemm192_kernel<*>', 'gemm192_kernelILi')):
-        mem = [k for k in ks if k.startswith(pat)]
+    for fam, pats in (('gemm256_kernel<false, 2, *>', ('gemm256_kernelILb0ELi2ELi', 'gemm256_kernel<false, 2, ')), ('gemm192_kernel<*>', ('gemm192_kernelILi', 'gemm192_kernel<'))):
+        mem = [k for k in ks if k.startswith(pats)]
         if mem:
             n = sum(ks[k]['launches'] for k in mem)
             ks[fam] = {'launches': n, 'members': mem, 'fetch_correction': 2,
