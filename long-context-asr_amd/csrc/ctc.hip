@@ -523,7 +523,13 @@ SCONF_API int sconf_ctc_fwd_logits(const float* logits, const int32_t* targets, 
     return 0;
 }
 
-constexpr int CTC_BWD_SLABS = 2048;
+SCONF_API int sconf_num_cus(void);
+static int ctc_bwd_slabs() {                            // workgroups of the fused gradient kernel (each keeps a slab of column sums)
+    static int v = 0;
+    if (!v) { const char* e = getenv("SCONF_CTC_BWD_SLABS"); v = e ? atoi(e) : 0; if (v < 64 || v > 65536) { const int n = sconf_num_cus(); v = 12 * (n > 0 ? n : 256); } }   // 6 resident per CU: whole rounds (2048: 2.78 ms, 3072: 2.63 at B = 128)
+    return v;
+}
+#define CTC_BWD_SLABS ctc_bwd_slabs()
 SCONF_API int64_t sconf_ctc_bwd_logits_workspace(int64_t rows, int64_t C) { return (int64_t)std::min<long>(rows, CTC_BWD_SLABS) * C; }
 // dlogits (B,N,C) bf16 = d nll / d logits (CTC gradient through log_softmax), scaled by grad_out[b] (null = 1).
 // colsum_out (optional, f32 [C], ACCUMULATED): column sums of dlogits - the decoder bias gradient; needs the workspace
