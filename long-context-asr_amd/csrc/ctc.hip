@@ -197,8 +197,9 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     // Frames are prefetched in groups of G (2 * G * MAXS registers): 4 at a few states per thread, 1 for the long lattices, whose
     // frames are slow enough to cover a load by themselves (with MAXS = 16 and groups of 4 the prefetch alone was 128 VGPRs of
     // the 128 a 1024-thread workgroup has: the kernel lived in scratch - 282 ms at N = 16384, S = 4096).
-    constexpr int G = MAXS <= 4 ? 4 : (MAXS <= 8 ? 2 : 1);
+    constexpr int G = MAXS <= 4 ? 4 : (MAXS <= 10 ? 2 : 1);
     constexpr int CH = MAXS <= 6 ? MAXS : (MAXS <= 12 ? MAXS / 2 : 4);   // recursions interleaved at a time (stage by stage)
+    constexpr bool COOP = MAXS > 4;                      // stored rows written cooperatively from the LDS row (below) instead of by the owning threads
     float pf[G][MAXS], nx[G][MAXS];
     // Unconditional loads from clamped (always valid) addresses: a load inside a branch is waited for inside that branch (vmcnt(0),
     // in order behind every store in flight) - eight serial memory round trips per group instead of a prefetch.  What the clamped
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                                 const float rel = (float)((double)v - A); // log2 units, relative to the frame's offset
                                 if (k0 + k < cnt) {
                                     cur[sp0 + k0 + k] = v;
-                                    orow[is_beta ? L - 1 - sp0 - k0 - k : sp0 + k0 + k] = rel * (float)LN2_D;
+                                    if (!COOP) orow[is_beta ? L - 1 - sp0 - k0 - k : sp0 + k0 + k] = rel * (float)LN2_D;
                                     mine = fmaxf(mine, rel);
                                 }
                             }
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 } else {
 #pragma unroll
                     for (int k = 0; k < MAXS; ++k)
-                        if (k < cnt) { cur[sp0 + k] = NEG; orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = -INFINITY; }
+                        if (k < cnt) { cur[sp0 + k] = NEG; if (!COOP) orow[is_beta ? L - 1 - sp0 - k : sp0 + k] = -INFINITY; }
                 }
                 if ((i & 3) == 3) {
                     mine = wave_max_dpp(mine);
@@ -300,6 +301,12 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                 CSTAMP(2);
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 CSTAMP(3);
+                // Long lattices (COOP): the row leaves for the gradient pass from its LDS copy, lanes on consecutive states (a thread's own MAXS states sit
+                // 4 MAXS bytes apart from its neighbour's: ten strided dword stores per thread and frame filled the memory pipeline of the
+                // 8 k-state lattices).  Row i & 1 is not written again before the barrier of frame i + 1.
+                if (COOP)
+                    for (int s = tid; s < L; s += nt)
+                        orow[is_beta ? L - 1 - s : s] = (float)((double)cur[s] - A) * (float)LN2_D;
             }
         }
 #pragma unroll
