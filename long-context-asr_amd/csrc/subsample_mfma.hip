@@ -472,13 +472,15 @@ int sconf_stage01_bwd_mfma(const void* dd1, const void* x, int x_dtype, const fl
     if ((F4 * C) % 8 != 0) return 0;
     const size_t gslot = (size_t)(F4 + 2) * 2 * C;
     const size_t sh = 2 * (size_t)PATCH_BYTES + 3 * gslot;
-    if (sh > 64 * 1024) return 0;
+    if (sh > 80 * 1024) return 0;                                                               // two workgroups per CU
     long target = 2048;
     if (const char* e = getenv("SCONF_SUB_BWD_BLOCKS")) target = atol(e);                       // tuning
     int rpb = std::max(2, (int)cdiv((long)T2 * B, target));
     rpb += rpb & 1;                                                                              // even: a block starts on an even conv0 row
     dim3 grid(cdiv(T2, rpb), (unsigned)B), block(512);
-#define LB(TX, NCB_) hipLaunchKernelGGL((stage01_bwd_mfma_kernel<TX, NCB_>), grid, block, sh, stream, (const TX*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb)
+#define LB(TX, NCB_) do { \
+        if (sh > 64 * 1024) { static bool attr = false; if (!attr) { (void)hipFuncSetAttribute((const void*)stage01_bwd_mfma_kernel<TX, NCB_>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024); attr = true; } } \
+        hipLaunchKernelGGL((stage01_bwd_mfma_kernel<TX, NCB_>), grid, block, sh, stream, (const TX*)x, w0, b0, wd, (const bf16*)dd1, dw0, db0, dwd, dbd, (int)F, (int)T, (int)C, T2, F2, T4, F4, rpb); } while (0)
     if (x_dtype == SCONF_F32) { if (C <= 256) LB(float, 1); else LB(float, 2); }
     else                      { if (C <= 256) LB(bf16, 1); else LB(bf16, 2); }
 #undef LB
