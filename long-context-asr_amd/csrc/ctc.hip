@@ -132,6 +132,21 @@ __global__ __launch_bounds__(256) void ctc_gather_kernel(const float* __restrict
     }
 }
 
+// LDS-DMA of 4 bytes per lane through a buffer descriptor, as inline asm: the builtin makes hipcc wait for EVERY pending DMA
+// (vmcnt(0)) in front of the next LDS read of any kind (attention.hip has the long story).  lds_base (uniform) + 4 * lane <- srd[voff].
+typedef __amdgpu_buffer_rsrc_t ctc_srd_t;
+__device__ __forceinline__ ctc_srd_t ctc_make_srd(const void* base, long nbytes) {
+    const unsigned long a = (unsigned long)base;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane((unsigned)(nbytes > 0xffffffffL ? 0xffffffffL : nbytes));
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(((unsigned long)hi << 32) | lo), 0, nb, 0x00020000);
+}
+__device__ __forceinline__ void ctc_dma_dword(ctc_srd_t srd, unsigned voff, unsigned soff, unsigned lds_base) {
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dword %3, %4, %1 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep), "+s"(soff), "+s"(lds_base) : "v"(voff), "s"(srd) : "memory");
+}
+
 // One workgroup per (sample, direction).  MAXS = max lattice states per thread; LT = type of the recursion's state (double; float
 // only for lattices that do not fit the LDS in f64).  The recursion runs in log2 units relative to nothing (absolute, in LT); what
 // is STORED for the gradient pass is natural-log, f32, relative to the frame's offset A_t (f64, written to offs), which follows the
@@ -197,9 +212,10 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
     // Frames are prefetched in groups of G (2 * G * MAXS registers): 4 at a few states per thread, 1 for the long lattices, whose
     // frames are slow enough to cover a load by themselves (with MAXS = 16 and groups of 4 the prefetch alone was 128 VGPRs of
     // the 128 a 1024-thread workgroup has: the kernel lived in scratch - 282 ms at N = 16384, S = 4096).
-    constexpr int G = MAXS <= 4 ? 4 : (MAXS <= 10 ? 2 : 1);
+    constexpr int G = MAXS <= 4 ? 4 : 1;
     constexpr int CH = MAXS <= 6 ? MAXS : (MAXS <= 12 ? MAXS / 2 : 4);   // recursions interleaved at a time (stage by stage)
     constexpr bool COOP = MAXS > 4;                      // stored rows written cooperatively from the LDS row (below) instead of by the owning threads
+    constexpr bool LONG = MAXS > 4;                      // emissions by LDS-DMA into a staging row (below); implies G == 1 ... 2 is folded to 1
     float pf[G][MAXS], nx[G][MAXS];
     // Unconditional loads from clamped (always valid) addresses: a load inside a branch is waited for inside that branch (vmcnt(0),
     // in order behind every store in flight) - eight serial memory round trips per group instead of a prefetch.  What the clamped
@@ -217,16 +233,54 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
             }
         }
     };
-    load_group(pf, 0);
+    // Long lattices (LONG): the emissions arrive by LDS-DMA, one frame ahead, instead of as MAXS strided dword loads per thread and
+    // frame (which, with the row stores, filled the memory pipeline: 3.4 k of 12 k cycles per frame went into ISSUING them).  Every
+    // blank state has the same emission, so what a wave needs is [blank, the labels of its own state range]: each wave stages exactly
+    // that into a segment of its own - its vmcnt(0) covers everything it reads, and no barrier orders the DMA against the reads.
+    constexpr int SEGN = 64 * (MAXS / 2 + 1);            // floats per wave segment: 1 + 32 MAXS (+ 1) entries, whole pieces of 64
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<char*>(wm) + 64) + wave * SEGN;
+    const unsigned stage_lds = (unsigned)(unsigned long)(__attribute__((address_space(3))) char*)stage;
+    // the wave's states in natural coordinates, and its first label
+    const int wsp0 = wave * 64 * MAXS, wsp1 = min(wsp0 + 64 * MAXS - 1, L - 1);
+    const int s_lo = is_beta ? L - 1 - wsp1 : wsp0, jl0 = max(s_lo, 0) >> 1;
+    auto dma_frame = [&](int i) {                          // frame i's emissions of this wave -> its segment
+        if (wsp0 >= L) return;
+        const int Tu = __builtin_amdgcn_readfirstlane(T), iu = __builtin_amdgcn_readfirstlane(i);
+        const int t = is_beta ? Tu - 1 - min(iu, Tu - 1) : min(iu, Tu - 1);
+        const ctc_srd_t esrd = ctc_make_srd(lg, (long)N * Lmax * 4);
 #pragma unroll
-    for (int j = 0; j < G; ++j)
+        for (int pc = 0; pc < MAXS / 2 + 1; ++pc) {
+            const int e = pc * 64 + (tid & 63);            // entry 0: the blank; entry e: label jl0 + e - 1
+            const int src = e == 0 ? 0 : 2 * min(jl0 + e - 1, max(S - 1, 0)) + 1;
+            ctc_dma_dword(esrd, (unsigned)(((long)t * Lmax + min(src, Lmax - 1)) * 4), 0u,        // (row offset in the per-lane part: < 4 GB per sample)
+                          (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + (unsigned)(pc * 256))));
+        }
+    };
+    auto read_stage = [&](float (&dst)[MAXS]) {
 #pragma unroll
-        for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(pf[j][k], -1e30f);
+        for (int k = 0; k < MAXS; ++k) {
+            const int sp = min(sp0 + k, L - 1), s_ = is_beta ? L - 1 - sp : sp;
+            dst[k] = fmaxf(stage[(s_ & 1) ? 1 + (s_ >> 1) - jl0 : 0], -1e30f);
+        }
+    };
+    if constexpr (LONG) {
+        dma_frame(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        read_stage(pf[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        dma_frame(1);
+    } else {
+        load_group(pf, 0);
+#pragma unroll
+        for (int j = 0; j < G; ++j)
+#pragma unroll
+            for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(pf[j][k], -1e30f);
+    }
     double A = 0.0;                                      // offset of the stored rows, log2 units
     CSTAMP_DECL
     const int w0 = wave * 64 * MAXS, w1 = w0 + 64 * MAXS - 1;   // the wave's range of states
     for (int i0 = 0; i0 < T; i0 += G) {
-        load_group(nx, i0 + G);                          // prefetch the next G time steps
+        if constexpr (!LONG) load_group(nx, i0 + G);     // prefetch the next G time steps
         CSTAMP(4);
 #pragma unroll
         for (int j = 0; j < G; ++j) {
@@ -299,23 +353,37 @@ __global__ __launch_bounds__(1024) void ctc_alphabeta_kernel(const float* __rest
                     if ((tid & 63) == 0) wm[wave] = mine;
                 }
                 CSTAMP(2);
+                if constexpr (LONG) {                      // next frame's emissions (DMA issued a frame ago by this wave), then the frame after
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    read_stage(nx[0]);
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the segment has been read: it may be overwritten
+                    dma_frame(i + 2);
+                }
                 asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
                 CSTAMP(3);
                 // Long lattices (COOP): the row leaves for the gradient pass from its LDS copy, lanes on consecutive states (a thread's own MAXS states sit
                 // 4 MAXS bytes apart from its neighbour's: ten strided dword stores per thread and frame filled the memory pipeline of the
                 // 8 k-state lattices).  Row i & 1 is not written again before the barrier of frame i + 1.
-                if (COOP)
-                    for (int s = tid; s < L; s += nt)
-                        orow[is_beta ? L - 1 - s : s] = (float)((double)cur[s] - A) * (float)LN2_D;
+                if (COOP) {                                 // (all LDS reads first: as a rolled loop each of the <= MAXS rounds waited for its own read)
+                    LT rv[MAXS];
+#pragma unroll
+                    for (int k = 0; k < MAXS; ++k) rv[k] = cur[min(tid + k * nt, L - 1)];
+#pragma unroll
+                    for (int k = 0; k < MAXS; ++k) {
+                        const int s = tid + k * nt;
+                        if (s < L) orow[is_beta ? L - 1 - s : s] = (float)((double)rv[k] - A) * (float)LN2_D;
+                    }
+                }
             }
         }
 #pragma unroll
         for (int j = 0; j < G; ++j)
 #pragma unroll
-            for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(nx[j][k], -1e30f);            // an emission of -inf must stay finite in the recursion
+            for (int k = 0; k < MAXS; ++k) pf[j][k] = fmaxf(nx[j][k], -1e30f);            // an emission of -inf must stay finite in the recursion (LONG: clamped already)
         CSTAMP(5);
     }
     CSTAMP_OUT;
+    if constexpr (LONG) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // no staging DMA in flight when the waves end
     if (!is_beta && tid == 0) {
         const LT* last = lat + ((T - 1) & 1) * W + 2;
         const double v = -(double)lse3_log2(last[L - 1], L > 1 ? last[L - 2] : NEG, NEG) * LN2_D;
@@ -484,8 +552,9 @@ static int ctc_fwd_impl(const char* who, bool from_logits, const float* in, floa
     if (const char* e = getenv("SCONF_CTC_THREADS")) { const int v = atoi(e); if (v == 256 || v == 512 || v == 1024) nt = v; }   // tuning
     const int spt = cdiv(Lmax, nt);
     const int spt_pad = spt <= 4 ? spt : spt <= 6 ? 6 : spt <= 8 ? 8 : spt <= 10 ? 10 : spt <= 12 ? 12 : 16;   // MAXS of the instantiation taken below
-    const bool f64_state = ((size_t)2 * (Lmax + spt_pad + 2)) * 8 + 144 <= 160 * 1024;        // else f32 state (lattices of more than ~10200 states)
-    const size_t sh = ((size_t)2 * (Lmax + spt_pad + 2)) * (f64_state ? 8 : 4) + 144;
+    const size_t stage = spt_pad > 4 ? (size_t)(nt / 64) * 64 * (spt_pad / 2 + 1) * 4 + 64 : 0;      // per-wave emission staging segments of the long-lattice form
+    const bool f64_state = ((size_t)2 * (Lmax + spt_pad + 2)) * 8 + 144 + stage <= 160 * 1024;        // else f32 state (lattices of more than ~9000 states)
+    const size_t sh = ((size_t)2 * (Lmax + spt_pad + 2)) * (f64_state ? 8 : 4) + 144 + stage;
     SCONF_REQUIRE(spt <= 16, "%s: target too long (%ld labels)", who, (long)Smax);
 #define L2(MS, LT) do { \
         if (sh > 48 * 1024) (void)hipFuncSetAttribute((const void*)ctc_alphabeta_kernel<MS, LT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh); \
