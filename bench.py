@@ -56,7 +56,7 @@ CONFIGS = {
     'c4': dict(model=dict(vocab_size=4095, n_layers=9, d_model=768, n_heads=6, head_dim=128, subsampling_conv_channels=256,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
                           default_norm='layer_norm', bias_in_ff=False, checkpoint_every_n_layers=1, ff_checkpoint_lvl=2),
-               T=16384, batch=64, name='9L/768D/6H SConformerXL, seq=16384, per-layer checkpointing'),
+               T=16384, batch=128, name='9L/768D/6H SConformerXL, seq=16384, per-layer checkpointing'),     # 3.73 M frames/s (batch 64: 3.65 M)
     # BASELINE.json configs[4]: exp_set_seq_rotary_base_3l_2048.yaml:27-53 (20-minute context)
     'c5': dict(model=dict(vocab_size=4095, n_layers=3, d_model=2048, n_heads=16, head_dim=128, subsampling_conv_channels=512,
                           use_rotary=True, rotary_base_freq=1500000, decoder_norm=True, self_conditioning=True,
