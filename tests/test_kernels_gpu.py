@@ -678,6 +678,31 @@ def test_ctc_at_the_131072_frame_context_against_the_f64_oracle(ops):
     assert rel2 < 2.5e-3 and rows2 < 4e-3, (rel2, rows2)
 
 
+def test_ctc_long_lattice_form_with_ragged_samples(ops):
+    """The long-lattice form of the CTC recursion (more than 4 states per thread: rows stored cooperatively from LDS, emissions staged
+    per wave by LDS-DMA) on a RAGGED batch: a full-length sample, a short one whose states fit the first wave (the other waves stage
+    and compute nothing), an empty target, and input lengths below N - against the f64 oracle, sample by sample."""
+    import sys
+    sys.path.insert(0, '.')
+    from oracle import ctc_ref
+    N, C, Smax = 2560, 64, 2304                                                    # 4609 states -> 5 per thread -> the 6-state instantiation
+    g = torch.Generator().manual_seed(11)
+    lg = torch.randn(3, N, C, generator=g)
+    tg = torch.randint(0, C - 1, (3, Smax), generator=g, dtype=torch.int32)
+    il = torch.tensor([N, 1200, 17], dtype=torch.int32); tl = torch.tensor([Smax, 40, 0], dtype=torch.int32)
+    lp = torch.log_softmax(lg.double(), -1).float()
+    nll, ws = ops.ctc_fwd(dev(lp), dev(tg), dev(il), dev(tl), C - 1)
+    grad = ops.ctc_bwd(dev(lp), ws, nll, dev(tg), dev(il), dev(tl), None, C - 1).cpu()
+    for b in range(3):
+        T, S = int(il[b]), int(tl[b])
+        nll_ref, grad_ref = ctc_ref.ctc_loss_and_grad_vec(lp[b, :T].double().numpy(), tg[b].numpy(), T, S, C - 1, out_dtype=np.float32)
+        assert abs(float(nll[b]) - nll_ref) <= 1e-5 * abs(nll_ref) + 1e-4, (b, float(nll[b]), nll_ref)
+        gr = torch.from_numpy(grad_ref)
+        rel = float((grad[b, :T].double() - gr.double()).norm() / gr.double().norm())
+        assert rel < 1e-3, (b, rel)
+        assert float(grad[b, T:].abs().max()) == 0.0 if T < N else True
+
+
 def test_ctc_edge_cases(ops):
     """torch.nn.CTCLoss(zero_infinity=False) semantics the reference relies on (exp/train.py:104): an EMPTY target is the
     all-blank path; an alignment that cannot fit (repeats need a blank in between) gives nll = +inf, a NaN gradient inside
