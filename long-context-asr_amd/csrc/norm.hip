@@ -85,12 +85,12 @@ template <typename T> __device__ __forceinline__ void raw_load(Raw4<T>& r, const
 template <typename TI, typename TG, int MAXIT> struct BwdRow {
     Raw4<TI> x[MAXIT]; Raw4<TG> g[MAXIT]; Raw4<float> r[MAXIT]; float mean, rstd;
     template <int MODE> __device__ __forceinline__ void load(const TG* dy, const TI* xp, const float* stat_mean, const float* stat_rstd,
-                                                             const float* dres, int row, int d, int lane) {
+                                                             const float* dres, int row, int d, int lane, int coff = 0) {
         mean = (MODE == 0) ? stat_mean[row] : 0.f;
         rstd = stat_rstd[row];
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int c = it * 256 + lane * 4;
+            const int c = coff + it * 256 + lane * 4;
             if (c < d) {
                 raw_load(x[it], xp + (long)row * d + c); raw_load(g[it], dy + (long)row * d + c);
                 if (dres) raw_load(r[it], dres + (long)row * d + c);
@@ -103,38 +103,46 @@ template <typename TI, typename TG, int MAXIT> struct BwdRow {
 // statistics) are issued before the current row's reductions, so the HBM latency overlaps the dependent wave_sum chains.
 // SLAB: the workgroup's column sums go to ws[blockIdx][dw | db][d] (plain stores; norm_bwd_reduce_kernel adds them up) instead
 // of atomics: all workgroups finish together and 512 x 2d atomics on 2d addresses serialise at the end of the kernel.
-template <typename TI, typename TG, typename TO, int MODE, int MAXIT, int NB_WAVES, bool AHEAD, bool SLAB>
+// CS = 2 (rows wider than 1024): a PAIR of waves per row, each MAXIT * 256 columns of it - with one wave per 2048-wide row the four
+// per-column accumulators alone are 128 registers and the kernel spilled 146-217 VGPRs (2.6 TB/s); the two row sums are exchanged
+// through LDS (one barrier per row; every wave runs the same number of trips).
+template <typename TI, typename TG, typename TO, int MODE, int MAXIT, int NB_WAVES, bool AHEAD, bool SLAB, int CS = 1>
 __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __restrict__ dy, const TI* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ stat_mean,
                                                        const float* __restrict__ stat_rstd, const float* __restrict__ dres,
                                                        TO* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db,
                                                        float* __restrict__ ws, bf16* __restrict__ dx16, int M, int d, float eps) {
     const int lane = threadIdx.x & 63;
-    const int wid = blockIdx.x * NB_WAVES + (threadIdx.x >> 6), nw = gridDim.x * NB_WAVES;
+    const int wv_ = threadIdx.x >> 6, half = CS == 2 ? (wv_ & 1) : 0, coff = half * (MAXIT * 256);
+    const int wid = (blockIdx.x * NB_WAVES + wv_) / CS, nw = gridDim.x * NB_WAVES / CS;
+    __shared__ float xs[2][NB_WAVES][2];               // CS == 2: the two partial row sums of a wave, double-buffered by trip
     // dx16 (SLAB only): a bf16 copy of dx for the GEMMs of the block that receives dx as its output gradient, and the column
     // sums of that copy (that block's output-projection bias gradient) - saves it a cast pass and a column-sum pass over dx.
     float aw[MAXIT][4], ab[MAXIT][4], wv[MAXIT][4], ac[MAXIT][4];
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
-        const int c = it * 256 + lane * 4;
+        const int c = coff + it * 256 + lane * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { aw[it][e] = 0.f; ab[it][e] = 0.f; wv[it][e] = 0.f; ac[it][e] = 0.f; }
         if (c < d) load4(w + c, wv[it]);
     }
     BwdRow<TI, TG, MAXIT> nxt;
-    if (AHEAD && wid < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, wid, d, lane);
-    for (int row = wid; row < M; row += nw) {
+    if (AHEAD && wid < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, wid, d, lane, coff);
+    const int trips = CS == 2 ? (M + nw - 1) / nw : 0;  // CS == 2: uniform over the workgroup (a barrier per trip); rows past M are clamped and not stored
+    for (int row = wid, tr = 0; CS == 2 ? tr < trips : row < M; row += nw, ++tr) {
+        const bool live = row < M;
+        const int rowc = CS == 2 ? min(row, M - 1) : row;
         BwdRow<TI, TG, MAXIT> cur;
         if (AHEAD) {
             cur = nxt;
-            if (row + nw < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, row + nw, d, lane);
-        } else cur.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, row, d, lane);
+            if (row + nw < M) nxt.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, row + nw, d, lane, coff);
+        } else cur.template load<MODE>(dy, x, stat_mean, stat_rstd, dres, rowc, d, lane, coff);
         const float mean = cur.mean, rstd = cur.rstd;
         float xh[MAXIT][4], g[MAXIT][4];
         float s1 = 0.f, s2 = 0.f;                    // sum(g*w), sum(g*w*xhat)  (xhat = raw x for RMS modes)
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int c = it * 256 + lane * 4;
+            const int c = coff + it * 256 + lane * 4;
             if (c < d) {
                 cur.x[it].get(xh[it]); cur.g[it].get(g[it]);
 #pragma unroll
@@ -143,23 +151,30 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
                     xh[it][e] = xn;
                     const float gw = g[it][e] * wv[it][e];
                     s1 += gw; s2 += gw * xn;
-                    aw[it][e] += g[it][e] * ((MODE == 0) ? xn : xn * rstd);
-                    ab[it][e] += g[it][e];
+                    if (CS == 1 || live) {
+                        aw[it][e] += g[it][e] * ((MODE == 0) ? xn : xn * rstd);
+                        ab[it][e] += g[it][e];
+                    }
                 }
             }
         }
         s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (CS == 2) {                                  // the partner wave holds the other half of the row
+            if (lane == 0) { xs[tr & 1][wv_][0] = s1; xs[tr & 1][wv_][1] = s2; }
+            __syncthreads();
+            s1 += xs[tr & 1][wv_ ^ 1][0]; s2 += xs[tr & 1][wv_ ^ 1][1];
+        }
         float c1, c2;                                 // dx = rstd*gw - c1 - xn*c2
         if (MODE == 0) { c1 = rstd * s1 / d; c2 = rstd * s2 / d; }
         else if (MODE == 1) {                         // y = w x / (rms+eps);  rstd = 1/(rms+eps)
             const float rms = 1.f / rstd - eps;
             c1 = 0.f; c2 = (rms > 0.f) ? s2 * rstd * rstd / (d * rms) : 0.f;
         } else { c1 = 0.f; c2 = s2 * rstd * rstd * rstd / d; }
-        TO* dxr = dx + (long)row * d;
+        TO* dxr = dx + (long)rowc * d;
 #pragma unroll
         for (int it = 0; it < MAXIT; ++it) {
-            const int c = it * 256 + lane * 4;
-            if (c < d) {
+            const int c = coff + it * 256 + lane * 4;
+            if (c < d && (CS == 1 || live)) {
                 float o[4];
                 float r[4] = {0.f, 0.f, 0.f, 0.f};
                 if (dres) cur.r[it].get(r);
@@ -167,7 +182,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
                 for (int e = 0; e < 4; ++e) o[e] = r[e] + rstd * g[it][e] * wv[it][e] - c1 - xh[it][e] * c2;
                 store4(dxr + c, o);
                 if (SLAB && dx16) {
-                    store4(dx16 + (long)row * d + c, o);
+                    store4(dx16 + (long)rowc * d + c, o);
 #pragma unroll
                     for (int e = 0; e < 4; ++e) ac[it][e] += (float)(bf16)o[e];
                 }
@@ -181,7 +196,7 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
 #pragma unroll
     for (int it = 0; it < MAXIT; ++it) {
         if (it * 256 >= d) break;                                   // uniform
-        const int c = it * 256 + lane * 4;
+        const int c = coff + it * 256 + lane * 4;
 #pragma unroll
         for (int pass = 0; pass < 3; ++pass) {
             if (pass == 1 && !(MODE == 0 && db)) continue;          // uniform
@@ -190,13 +205,13 @@ __global__ __launch_bounds__(64 * NB_WAVES) void norm_bwd_kernel(const TG* __res
 #pragma unroll
             for (int e = 0; e < 4; ++e) red[wvi][lane * 4 + e] = pass == 0 ? aw[it][e] : (pass == 1 ? ab[it][e] : ac[it][e]);
             __syncthreads();
-            if (wvi == 0 && c < d) {
+            if (wvi < CS && c < d) {                                // wave 0 (and, CS == 2, wave 1 for the upper half of the columns)
                 float v[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     v[e] = 0.f;
 #pragma unroll
-                    for (int k = 0; k < NB_WAVES; ++k) v[e] += red[k][lane * 4 + e];
+                    for (int k = wvi; k < NB_WAVES; k += CS) v[e] += red[k][lane * 4 + e];
                 }
                 if (SLAB) store4(ws + ((long)blockIdx.x * 3 + pass) * d + c, v);
                 else {
@@ -267,11 +282,13 @@ template <int MODE, int NIT>
 int launch_bwd(const void* dy, int gdt, const void* x, int xdt, const float* w, const float* mean, const float* rstd,
                const float* dres, void* dx, int odt, float* dw, float* db, float* ws, long ws_floats, bf16* dx16, float* dx_colsum,
                int M, int d, float eps, hipStream_t st) {
-    constexpr bool AHEAD = NIT <= 4;
-    dim3 grid(min(cdiv(M, NBW), bwd_maxgrid())), block(64 * NBW);
+    constexpr int CS = NIT > 4 ? 2 : 1, WIT = NIT / CS;          // rows wider than 1024: a pair of waves per row (WIT * 256 columns each)
+    static_assert(NIT <= 4 || NIT % 2 == 0, "wide rows are split in two equal column halves");
+    constexpr bool AHEAD = true;
+    dim3 grid(min(cdiv(M * CS, NBW), bwd_maxgrid())), block(64 * NBW);
     const bool slab = ws && ws_floats >= (long)grid.x * 3 * d;
     if (!slab) { dx16 = nullptr; dx_colsum = nullptr; }
-#define L4(TI, TG, TO, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, NIT, NBW, AHEAD, SL>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, dx16, M, d, eps)
+#define L4(TI, TG, TO, SL) hipLaunchKernelGGL((norm_bwd_kernel<TI, TG, TO, MODE, WIT, NBW, AHEAD, SL, CS>), grid, block, 0, st, (const TG*)dy, (const TI*)x, w, mean, rstd, dres, (TO*)dx, dw, db, ws, dx16, M, d, eps)
 #define L(TI, TG, TO) do { if (slab) L4(TI, TG, TO, true); else L4(TI, TG, TO, false); } while (0)
     if (xdt == SCONF_F32) {
         if (gdt == SCONF_F32) { if (odt == SCONF_F32) L(float, float, float); else L(float, float, bf16); }
@@ -603,7 +620,7 @@ SCONF_API int sconf_norm_fwd(int mode, const void* x, int x_dtype, const float* 
 // sconf_norm_bwd_workspace(M, d) floats, contents irrelevant) receives per-workgroup column sums that a second kernel adds
 // into dweight/dbias in a fixed order; without it the workgroups fall back to f32 atomics (slower, order not fixed).
 SCONF_API int64_t sconf_norm_bwd_workspace(int64_t M, int64_t d) {
-    return (int64_t)min(cdiv(M, NBW), bwd_maxgrid()) * 3 * d;
+    return (int64_t)min(cdiv(M * (d > 1024 ? 2 : 1), NBW), bwd_maxgrid()) * 3 * d;        // (rows wider than 1024: two waves per row)
 }
 SCONF_API int sconf_norm_bwd(int mode, const void* dy, int dy_dtype, const void* x, int x_dtype, const float* weight,
                              const float* mean, const float* rstd, const float* dres, void* dx, int dx_dtype,

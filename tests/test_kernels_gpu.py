@@ -215,7 +215,7 @@ def test_gemm_rejects_bad_shapes(ops):
 
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize('mode', ['layer_norm', 'rms_norm', 'rms_norm_apex'])
-@pytest.mark.parametrize('d', [64, 256, 768, 2048])
+@pytest.mark.parametrize('d', [64, 256, 768, 1280, 2048])
 def test_norm_fwd_bwd(ops, mode, d):
     M = 77
     eps = 1e-8 if mode == 'rms_norm' else 1e-5

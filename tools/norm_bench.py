@@ -3,7 +3,7 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import lcasr_amd.hip.ops as ops
-M, d = 32768, 768
+M, d = int(os.environ.get('NORM_M', '32768')), int(os.environ.get('NORM_D', '768'))
 x = torch.randn(M, d, device='cuda'); w = torch.randn(d, device='cuda'); b = torch.randn(d, device='cuda')
 y, mean, rstd = ops.norm_fwd(x, w, b, 'layer_norm', 1e-5, torch.bfloat16)
 dres = torch.randn(M, d, device='cuda'); dw = torch.zeros(d, device='cuda'); db = torch.zeros(d, device='cuda')
